@@ -1,0 +1,316 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE on CPU.
+
+Authoring-container only (needs /root/reference); run as ``python -m oracle.make_golden [names...]``.
+Every fixture is data: seeds, the small inputs that are not exactly regenerable, and the outputs of
+the reference's own classes (UNetModel, ResBlock, SpatialTransformer, CrossAttention, FeedForward,
+Downsample, Upsample, GroupNorm32, Normalize, DDIMSampler, LatentDiffusion, AutoencoderKL) fed with
+weights from the build's deterministic synthesiser.  Nothing of the reference's text is stored.
+"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.ref_import import import_reference  # noqa: E402
+
+S = importlib.import_module("stable-diffusion_amd.structure")
+synth = importlib.import_module("stable-diffusion_amd.synth")
+GOLD = os.path.join(ROOT, "tests", "golden")
+WSEED = 0
+
+
+def save(name, **arrs):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)", flush=True)
+
+
+def f16r(t):
+    """Round to fp16-representable values (so the fp16 device path sees exact inputs)."""
+    return t.half().float()
+
+
+def load_module(mod, prefix_key, seed=WSEED):
+    """Fill a reference nn.Module with synthesised weights keyed by ``prefix_key + name``."""
+    sd = {k: synth.synth_tensor(seed, prefix_key + k, v.shape) for k, v in mod.state_dict().items()}
+    mod.load_state_dict(sd)
+    return mod.eval()
+
+
+def make_inputs_unet(b, cin, hw, tval, seed_x=42):
+    x = synth.normal(seed_x, "x_T", (b, cin, hw, hw))
+    ctx = f16r(torch.cat([synth.normal(2, "uncond_ctx", (b // 2 if b > 1 else 1, 77, 768)),
+                          synth.normal(1, "cond_ctx", (b // 2 if b > 1 else 1, 77, 768))])[:b])
+    t = torch.full((b,), tval, dtype=torch.long)
+    return x, t, ctx
+
+
+@torch.no_grad()
+def g1(sdm):
+    t = torch.tensor([0, 1, 500, 981], dtype=torch.long)
+    save("g1_timestep_embedding", t=t, emb=sdm.timestep_embedding(t, 320))
+
+
+@torch.no_grad()
+def g2(sdm):
+    out = {}
+    u = lambda key, shape, lo=-2., hi=2.: synth.uniform(7, "g2." + key, shape, lo, hi)
+    emb = u("emb", (2, 1280))
+    ctx = u("ctx", (2, 77, 768))
+    # ResBlocks (prefix keys follow the UNet naming so the device test can reuse its loader)
+    rb = load_module(sdm.ResBlock(320, 1280, 0., out_channels=320), "g2.res_a.")
+    out["res_a"] = rb(u("res_a.x", (2, 320, 8, 8)), emb)
+    rb = load_module(sdm.ResBlock(640, 1280, 0., out_channels=320), "g2.res_b.")
+    out["res_b"] = rb(u("res_b.x", (2, 640, 8, 8)), emb)
+    st = load_module(sdm.SpatialTransformer(320, 8, 40, depth=1, context_dim=768), "g2.st.")
+    out["st"] = st(u("st.x", (2, 320, 8, 8)), ctx)
+    for dh in (40, 80, 160):
+        d = 8 * dh
+        ca = load_module(sdm.CrossAttention(d, None, heads=8, dim_head=dh), f"g2.self{dh}.")
+        out[f"self{dh}"] = ca(u(f"self{dh}.x", (2, 64, d)))
+        ca = load_module(sdm.CrossAttention(d, 768, heads=8, dim_head=dh), f"g2.cross{dh}.")
+        out[f"cross{dh}"] = ca(u(f"cross{dh}.x", (2, 64, d)), context=ctx)
+    ff = load_module(sdm.FeedForward(320, glu=True), "g2.ff.")
+    out["ff"] = ff(u("ff.x", (2, 64, 320)))
+    dn = load_module(sdm.Downsample(320, True), "g2.down.")
+    out["down"] = dn(u("down.x", (2, 320, 8, 8)))
+    up = load_module(sdm.Upsample(320, True), "g2.up.")
+    out["up"] = up(u("up.x", (2, 320, 8, 8)))
+    gn = load_module(sdm.normalization(320), "g2.gn32.norm.")
+    out["gn32_silu"] = torch.nn.functional.silu(gn(u("gn32.x", (2, 320, 8, 8))))
+    gn = load_module(sdm.Normalize(640), "g2.normalize.norm.")
+    out["normalize"] = gn(u("normalize.x", (2, 640, 8, 8)))
+    ln = load_module(torch.nn.LayerNorm(320), "g2.ln.norm.")
+    out["layernorm"] = ln(u("ln.x", (2, 64, 320)))
+    save("g2_blocks", **out)
+
+
+def ref_unet(sdm, cfg):
+    st = S.unet_structure(**cfg)
+    shapes = S.unet_param_shapes(st)
+    net = sdm.UNetModel(**cfg).eval()
+    rsd = net.state_dict()
+    assert set(rsd.keys()) == set(shapes.keys())
+    for k, v in rsd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    net.load_state_dict(synth.synth_state_dict(shapes, WSEED))
+    return net
+
+
+@torch.no_grad()
+def g3(sdm, which=("c2", "c1", "c5")):
+    net4 = ref_unet(sdm, S.sd_v1_unet_config(4))
+    blocks = list(net4.input_blocks) + [net4.middle_block] + list(net4.output_blocks)
+    if "c2" in which:
+        stats = []
+        hooks = [m.register_forward_hook(
+            lambda m, i, o: stats.append([float(o.mean()), float(o.abs().max()), float(o.norm())]))
+            for m in blocks]
+        x, t, ctx = make_inputs_unet(2, 4, 64, 981)
+        t0 = time.time()
+        out = net4(x, t, context=ctx)
+        print(f"c2 forward {time.time() - t0:.1f}s", flush=True)
+        for h in hooks:
+            h.remove()
+        save("g3_unet_c2", x=x, t=t, ctx=ctx.half(), out=out, taps=np.asarray(stats, dtype=np.float64))
+    if "c1" in which:
+        x, t, ctx = make_inputs_unet(1, 4, 32, 901)
+        save("g3_unet_c1", x=x, t=t, ctx=ctx.half(), out=net4(x, t, context=ctx))
+    del net4
+    if "c5" in which:
+        net9 = ref_unet(sdm, S.sd_v1_unet_config(9))
+        wrap = sdm.DiffusionWrapper.__new__(sdm.DiffusionWrapper)
+        torch.nn.Module.__init__(wrap)
+        wrap.diffusion_model = net9
+        wrap.conditioning_key = "hybrid"
+        x, t, ctx = make_inputs_unet(2, 4, 96, 981)
+        mask = (synth.uniform01(5, "mask", 96 * 96).reshape(1, 1, 96, 96) > 0.5).float().repeat(2, 1, 1, 1)
+        masked = synth.normal(6, "masked_latent", (1, 4, 96, 96)).repeat(2, 1, 1, 1)
+        t0 = time.time()
+        out = wrap(x, t, c_concat=[[mask], [masked]], c_crossattn=[ctx])
+        print(f"c5 forward {time.time() - t0:.1f}s", flush=True)
+        save("g3_unet_c5", x=x, t=t, ctx=ctx.half(), mask=mask, masked=masked, out=out)
+
+
+def ref_latent_diffusion(sdm, in_channels=4, conditioning_key="crossattn"):
+    params = S.sd_v1_model_params(in_channels, conditioning_key)
+    params["timesteps"] = 1000
+    model = sdm.LatentDiffusion(**params).eval()
+    ust = S.unet_structure(**params["unet_config"])
+    model.model.diffusion_model.load_state_dict(synth.synth_state_dict(S.unet_param_shapes(ust), WSEED))
+    vst = S.vae_decoder_structure(params["first_stage_config"]["ddconfig"], 4)
+    missing, unexpected = model.first_stage_model.load_state_dict(
+        synth.synth_state_dict(S.vae_decoder_param_shapes(vst), WSEED), strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith(("encoder.", "quant_conv.")) for k in missing), missing
+    return model
+
+
+@torch.no_grad()
+def g4(sdm, model=None):
+    model = model or ref_latent_diffusion(sdm)
+    out = {"betas": model.betas, "alphas_cumprod": model.alphas_cumprod,
+           "alphas_cumprod_prev": model.alphas_cumprod_prev,
+           "sqrt_alphas_cumprod": model.sqrt_alphas_cumprod,
+           "sqrt_one_minus_alphas_cumprod": model.sqrt_one_minus_alphas_cumprod}
+    sampler = sdm.DDIMSampler(model)
+    for Sn in (10, 50):
+        for eta in (0.0, 0.5):
+            sampler.make_schedule(Sn, ddim_eta=eta, verbose=False)
+            tag = f"S{Sn}_eta{eta}"
+            out[f"{tag}.timesteps"] = np.asarray(sampler.ddim_timesteps)
+            for n in ("ddim_alphas", "ddim_alphas_prev", "ddim_sigmas", "ddim_sqrt_one_minus_alphas"):
+                v = getattr(sampler, n)
+                print(tag, n, type(v), getattr(v, "dtype", None))
+                out[f"{tag}.{n}"] = np.asarray(v, dtype=np.float64)
+    save("g4_schedules", **out)
+    return model
+
+
+@torch.no_grad()
+def g5(sdm, model):
+    """p_sample_ddim / stochastic_encode / q_sample known answers with a stub eps model."""
+    sampler = sdm.DDIMSampler(model)
+    b = 2
+    x = synth.normal(11, "g5.x", (b, 4, 16, 16))
+    e_u = synth.normal(12, "g5.eu", (b, 4, 16, 16))
+    e_c = synth.normal(13, "g5.ec", (b, 4, 16, 16))
+    noise = synth.normal(14, "g5.noise", (b, 4, 16, 16))
+    out = {"x": x, "e_u": e_u, "e_c": e_c, "noise": noise}
+    orig_apply, orig_noise = model.apply_model, sdm.noise_like
+    model.apply_model = lambda x_in, t_in, c: torch.cat([e_u, e_c])
+    sdm.noise_like = lambda shape, device, repeat=False: noise
+    try:
+        for eta in (0.0, 0.5):
+            sampler.make_schedule(50, ddim_eta=eta, verbose=False)
+            for index in (49, 20, 0):
+                t = torch.full((b,), int(sampler.ddim_timesteps[index]), dtype=torch.long)
+                xp, p0 = sampler.p_sample_ddim(x, None, t, index=index, unconditional_guidance_scale=7.5,
+                                               unconditional_conditioning=True)
+                out[f"eta{eta}.i{index}.x_prev"], out[f"eta{eta}.i{index}.pred_x0"] = xp, p0
+        sampler.make_schedule(50, ddim_eta=0.0, verbose=False)
+        for tidx in (36, 49):
+            out[f"stochastic_encode.t{tidx}"] = sampler.stochastic_encode(
+                x, torch.tensor([tidx] * b), noise=noise)
+        tq = torch.tensor([981, 1], dtype=torch.long)
+        out["q_sample.t981_1"] = model.q_sample(x, tq, noise=noise)
+    finally:
+        model.apply_model, sdm.noise_like = orig_apply, orig_noise
+    save("g5_sampler_kat", **out)
+
+
+def cfg_context(b):
+    uc = f16r(synth.normal(2, "uncond_ctx", (b, 77, 768)))
+    c = f16r(synth.normal(1, "cond_ctx", (b, 77, 768)))
+    return uc, c
+
+
+@torch.no_grad()
+def g6(sdm, model):
+    """C1 end to end: 256x256, 10 DDIM steps, batch 1, CFG 7.5, eta 0, + VAE decode + clamp."""
+    sampler = sdm.DDIMSampler(model)
+    x_T = synth.normal(42, "x_T", (1, 4, 32, 32))
+    uc, c = cfg_context(1)
+    t0 = time.time()
+    z, _ = sampler.sample(S=10, batch_size=1, shape=[4, 32, 32], conditioning=torch.cat([uc, c]),
+                          unconditional_guidance_scale=7.5, unconditional_conditioning=True,
+                          eta=0., x_T=x_T, verbose=False)
+    img = torch.clamp((model.decode_first_stage(z) + 1.0) / 2.0, min=0.0, max=1.0)
+    print(f"g6 {time.time() - t0:.1f}s", flush=True)
+    save("g6_c1_e2e", x_T=x_T, uc=uc.half(), c=c.half(), z=z, image=img.half())
+
+
+@torch.no_grad()
+def g7(sdm, model):
+    """C3-shaped trajectory at batch 1: 512x512, 50 steps, CFG 7.5, eta 0 (the PSNR reference)."""
+    sampler = sdm.DDIMSampler(model)
+    x_T = synth.normal(42, "x_T", (1, 4, 64, 64))
+    uc, c = cfg_context(1)
+    inter = {}
+
+    def cb(pred_x0, i):
+        if i in (0, 9, 24, 49):
+            inter[f"pred_x0_step{i}"] = pred_x0.clone()
+        print(f"  g7 step {i}", flush=True)
+
+    t0 = time.time()
+    z, _ = sampler.sample(S=50, batch_size=1, shape=[4, 64, 64], conditioning=torch.cat([uc, c]),
+                          unconditional_guidance_scale=7.5, unconditional_conditioning=True,
+                          eta=0., x_T=x_T, verbose=False, img_callback=cb)
+    dec = model.decode_first_stage(z)
+    img = torch.clamp((dec + 1.0) / 2.0, min=0.0, max=1.0)
+    print(f"g7 {time.time() - t0:.1f}s", flush=True)
+    save("g7_c3_traj", x_T=x_T, uc=uc.half(), c=c.half(), z=z, image=img.half(), **inter)
+
+
+@torch.no_grad()
+def g8(sdm, model):
+    z = synth.normal(21, "g8.z", (1, 4, 32, 32))
+    save("g8_vae", z=z, dec=model.decode_first_stage(z), dec_raw=model.first_stage_model.decode(z))
+
+
+@torch.no_grad()
+def g9(sdm, model):
+    """img2img: stochastic_encode at t_enc-1... then decode() over t_enc=37 of S=50 steps (32x32 latent)."""
+    sampler = sdm.DDIMSampler(model)
+    sampler.make_schedule(50, ddim_eta=0.0, verbose=False)
+    init = synth.normal(31, "g9.init_latent", (1, 4, 32, 32)) * 0.8
+    noise = synth.normal(32, "g9.noise", (1, 4, 32, 32))
+    t_enc = int(0.75 * 50)
+    z_enc = sampler.stochastic_encode(init, torch.tensor([t_enc]), noise=noise)
+    uc, c = cfg_context(1)
+    t0 = time.time()
+    z = sampler.decode(z_enc, torch.cat([uc, c]), t_enc, unconditional_guidance_scale=5.0,
+                       unconditional_conditioning=True)
+    print(f"g9 img2img {time.time() - t0:.1f}s", flush=True)
+    save("g9_img2img", init=init, noise=noise, z_enc=z_enc, uc=uc.half(), c=c.half(), z=z)
+
+
+@torch.no_grad()
+def g9b(sdm):
+    """inpaint-with-text: hybrid 9-channel UNet, S=5 at 32x32 latent, CFG 7.5 (short)."""
+    model = ref_latent_diffusion(sdm, in_channels=9, conditioning_key="hybrid")
+    sampler = sdm.DDIMSampler(model)
+    x_T = synth.normal(42, "x_T", (1, 4, 32, 32))
+    mask = (synth.uniform01(5, "mask", 32 * 32).reshape(1, 1, 32, 32) > 0.5).float().repeat(2, 1, 1, 1)
+    masked = synth.normal(6, "masked_latent", (1, 4, 32, 32)).repeat(2, 1, 1, 1)
+    uc, c = cfg_context(1)
+    cond = {"c_concat": [[mask], [masked]], "c_crossattn": [torch.cat([uc, c])]}
+    z, _ = sampler.sample(S=5, batch_size=1, shape=[4, 32, 32], conditioning=cond,
+                          unconditional_guidance_scale=7.5, unconditional_conditioning=True,
+                          eta=0., x_T=x_T, verbose=False)
+    save("g9_inpaint", x_T=x_T, mask=mask, masked=masked, uc=uc.half(), c=c.half(), z=z)
+
+
+def main(argv):
+    names = argv or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g9b", "g7"]
+    torch.manual_seed(0)
+    sdm = import_reference()
+    model = None
+    need_model = {"g4", "g5", "g6", "g7", "g8", "g9"} & set(names)
+    for n in names:
+        t0 = time.time()
+        if n == "g1":
+            g1(sdm)
+        elif n == "g2":
+            g2(sdm)
+        elif n.startswith("g3"):
+            g3(sdm, tuple(n.split(":")[1].split(",")) if ":" in n else ("c2", "c1", "c5"))
+        elif n == "g9b":
+            g9b(sdm)
+        else:
+            if model is None and need_model:
+                model = ref_latent_diffusion(sdm)
+            {"g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9}[n](sdm, model)
+        print(f"[{n}] done in {time.time() - t0:.1f}s", flush=True)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

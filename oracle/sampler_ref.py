@@ -1,0 +1,102 @@
+"""fp32/float64 CPU restatement of the reference noise schedule and DDIM sampler
+(TEST INFRASTRUCTURE ONLY).  File cited = /root/reference/stable_diffusion.py.
+"""
+import numpy as np
+import torch
+
+
+def beta_schedule(linear_start, linear_end, n=1000):
+    """make_beta_schedule :3565-3567, "linear" = direct linspace of betas in float64."""
+    return torch.linspace(linear_start, linear_end, n, dtype=torch.float64).numpy()
+
+
+def ddpm_tables(linear_start=0.00085, linear_end=0.012, n=1000):
+    """DDPM.register_schedule :3755-3793 (the buffers the sampler reads), float64 -> fp32."""
+    betas = beta_schedule(linear_start, linear_end, n)
+    alphas = 1. - betas
+    ac = np.cumprod(alphas, axis=0)
+    ac_prev = np.append(1., ac[:-1])
+    f32 = lambda a: torch.tensor(a, dtype=torch.float32)
+    return {
+        "betas": f32(betas),
+        "alphas_cumprod": f32(ac),
+        "alphas_cumprod_prev": f32(ac_prev),
+        "sqrt_alphas_cumprod": f32(np.sqrt(ac)),
+        "sqrt_one_minus_alphas_cumprod": f32(np.sqrt(1. - ac)),
+    }
+
+
+def ddim_timesteps(S, n=1000):
+    """make_ddim_timesteps :5141-5153, "uniform"."""
+    c = n // S
+    return np.asarray(list(range(0, n, c))) + 1
+
+
+def ddim_tables(alphas_cumprod: torch.Tensor, S, eta):
+    """make_ddim_sampling_parameters :5155-5165 + make_schedule :5205-5211.
+
+    ``alphas_cumprod`` is the fp32 buffer; the selected values stay fp32, alphas_prev passes
+    through python floats (exactly the fp32 values) and the sigma formula runs in float64 on them.
+    """
+    ts = ddim_timesteps(S, alphas_cumprod.shape[0])
+    a = alphas_cumprod.numpy()[ts].astype(np.float32)
+    a_prev = np.asarray([float(alphas_cumprod[0])] + [float(v) for v in a[:-1]])
+    # :5160 mixes a float64 ndarray with an fp32 tensor: ndarray / tensor dispatches to the tensor's
+    # reflected division, which torch evaluates as reciprocal(tensor) * ndarray -- i.e. 1/(1-alphas)
+    # is rounded to fp32 before the float64 product.
+    recip = (np.float32(1.0) / (np.float32(1.0) - a)).astype(np.float64)
+    sig = eta * np.sqrt(recip * (1 - a_prev) * (1 - a.astype(np.float64) / a_prev))
+    return {"timesteps": ts, "alphas": a, "alphas_prev": a_prev, "sigmas": sig,
+            "sqrt_one_minus_alphas": np.sqrt(1. - a)}
+
+
+def ddim_update(x, e_t, a_t, a_prev, sigma_t, sqrt_1m_at, noise, temperature=1.):
+    """p_sample_ddim :5360-5375 with the four scalars already selected.
+
+    The reference materialises each scalar with torch.full (fp32) and does all arithmetic in fp32."""
+    f = lambda v: torch.full((x.shape[0], 1, 1, 1), float(v))
+    a_t, a_prev, sigma_t, sqrt_1m_at = f(a_t), f(a_prev), f(sigma_t), f(sqrt_1m_at)
+    pred_x0 = (x - sqrt_1m_at * e_t) / a_t.sqrt()
+    dir_xt = (1. - a_prev - sigma_t ** 2).sqrt() * e_t
+    n = sigma_t * noise * temperature
+    x_prev = a_prev.sqrt() * pred_x0 + dir_xt + n
+    return x_prev, pred_x0
+
+
+def cfg_combine(e_uncond, e_cond, scale):
+    """:5347."""
+    return e_uncond + scale * (e_cond - e_uncond)
+
+
+def stochastic_encode(x0, t_index, tab, noise):
+    """DDIMSampler.stochastic_encode :5378-5391 with ddim tables (use_original_steps=False)."""
+    sa = torch.sqrt(torch.as_tensor(tab["alphas"]))
+    s1 = torch.as_tensor(tab["sqrt_one_minus_alphas"])
+    t = torch.as_tensor(t_index, dtype=torch.long)
+    shp = (x0.shape[0], 1, 1, 1)
+    return sa.gather(-1, t).reshape(shp) * x0 + s1.gather(-1, t).reshape(shp) * noise
+
+
+@torch.no_grad()
+def ddim_loop(eps_model, x_T, S, eta, scale, tables_ddpm, noises=None, t_start=None):
+    """ddim_sampling :5276-5335 / decode :5394-5412 with the CFG contract: ``eps_model(x_in, t_in)``
+    receives the doubled batch [x; x] and returns eps for [uncond; cond] (:5344-5346).
+
+    t_start=None runs all S steps (sample); otherwise the first t_start timesteps (decode)."""
+    tab = ddim_tables(tables_ddpm["alphas_cumprod"], S, eta)
+    ts = tab["timesteps"] if t_start is None else tab["timesteps"][:t_start]
+    total = ts.shape[0]
+    img = x_T
+    b = x_T.shape[0]
+    for i, step in enumerate(np.flip(ts)):
+        index = total - i - 1
+        t = torch.full((b,), int(step), dtype=torch.long)
+        if scale != 1.:
+            e_u, e_c = eps_model(torch.cat([img] * 2), torch.cat([t] * 2)).chunk(2)
+            e_t = cfg_combine(e_u, e_c, scale)
+        else:
+            e_t = eps_model(img, t)
+        noise = noises[i] if noises is not None else torch.zeros_like(img)
+        img, _ = ddim_update(img, e_t, tab["alphas"][index], tab["alphas_prev"][index],
+                             tab["sigmas"][index], tab["sqrt_one_minus_alphas"][index], noise)
+    return img

@@ -1,0 +1,142 @@
+"""CPU: pin the oracle (oracle/*.py) against the golden vectors the reference itself produced.
+
+Tolerances: the oracle and the reference run the same fp32 torch-CPU primitives in (almost) the same
+order, so agreement is at rounding level; bounds below are max|a-b|/max|b|.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import golden, max_rel_err, g2_u, structure as S, synth
+from oracle import unet_ref, sampler_ref, vae_ref
+
+TIGHT = 2e-6
+
+
+def test_g1_timestep_embedding():
+    g = golden("g1_timestep_embedding")
+    emb = unet_ref.timestep_embedding(g["t"], 320)
+    assert emb.shape == (4, 320)
+    assert torch.equal(emb, g["emb"])
+
+
+def _res_sd(spec):
+    shapes = OrderedDict()
+    S._res_params(spec, 1280, shapes)
+    return synth.synth_state_dict(shapes, 0)
+
+
+def test_g2_resblocks():
+    g = golden("g2_blocks")
+    emb = g2_u("emb", (2, 1280))
+    for name, cin in (("res_a", 320), ("res_b", 640)):
+        spec = S.ResSpec("g2." + name, cin, 320)
+        out = unet_ref.res_block(g2_u(name + ".x", (2, cin, 8, 8)), emb, _res_sd(spec), spec)
+        assert max_rel_err(out, g[name]) < TIGHT, name
+
+
+def test_g2_spatial_transformer():
+    g = golden("g2_blocks")
+    spec = S.STSpec("g2.st", 320, 8, 40, 1, 768)
+    shapes = OrderedDict()
+    S._st_params(spec, shapes)
+    sd = synth.synth_state_dict(shapes, 0)
+    out = unet_ref.spatial_transformer(g2_u("st.x", (2, 320, 8, 8)), g2_u("ctx", (2, 77, 768)), sd, spec)
+    assert max_rel_err(out, g["st"]) < TIGHT
+
+
+@pytest.mark.parametrize("dh", [40, 80, 160])
+def test_g2_attention(dh):
+    g = golden("g2_blocks")
+    d = 8 * dh
+    ctx = g2_u("ctx", (2, 77, 768))
+    for kind, cdim, context in (("self", d, None), ("cross", 768, ctx)):
+        p = f"g2.{kind}{dh}"
+        shapes = {f"{p}.to_q.weight": (d, d), f"{p}.to_k.weight": (d, cdim), f"{p}.to_v.weight": (d, cdim),
+                  f"{p}.to_out.0.weight": (d, d), f"{p}.to_out.0.bias": (d,)}
+        sd = synth.synth_state_dict(shapes, 0)
+        out = unet_ref.attention(g2_u(f"{kind}{dh}.x", (2, 64, d)), context, sd, p, 8)
+        assert max_rel_err(out, g[f"{kind}{dh}"]) < TIGHT, p
+
+
+def test_g2_feedforward_resample_norms():
+    g = golden("g2_blocks")
+    p = "g2.ff"
+    sd = synth.synth_state_dict({f"{p}.net.0.proj.weight": (2560, 320), f"{p}.net.0.proj.bias": (2560,),
+                                 f"{p}.net.2.weight": (320, 1280), f"{p}.net.2.bias": (320,)}, 0)
+    assert max_rel_err(unet_ref.feed_forward(g2_u("ff.x", (2, 64, 320)), sd, p), g["ff"]) < TIGHT
+    sd = synth.synth_state_dict({"g2.down.op.weight": (320, 320, 3, 3), "g2.down.op.bias": (320,),
+                                 "g2.up.conv.weight": (320, 320, 3, 3), "g2.up.conv.bias": (320,)}, 0)
+    out = unet_ref._run_layers([S.DownSpec("g2.down.op", 320)], g2_u("down.x", (2, 320, 8, 8)), None, None, sd)
+    assert out.shape == (2, 320, 4, 4) and max_rel_err(out, g["down"]) < TIGHT
+    out = unet_ref._run_layers([S.UpSpec("g2.up.conv", 320)], g2_u("up.x", (2, 320, 8, 8)), None, None, sd)
+    assert out.shape == (2, 320, 16, 16) and max_rel_err(out, g["up"]) < TIGHT
+    sd = synth.synth_state_dict({"g2.gn32.norm.weight": (320,), "g2.gn32.norm.bias": (320,),
+                                 "g2.normalize.norm.weight": (640,), "g2.normalize.norm.bias": (640,),
+                                 "g2.ln.norm.weight": (320,), "g2.ln.norm.bias": (320,)}, 0)
+    out = unet_ref.silu(unet_ref.group_norm(g2_u("gn32.x", (2, 320, 8, 8)), sd, "g2.gn32.norm", 1e-5))
+    assert max_rel_err(out, g["gn32_silu"]) < TIGHT
+    out = unet_ref.group_norm(g2_u("normalize.x", (2, 640, 8, 8)), sd, "g2.normalize.norm", 1e-6)
+    assert max_rel_err(out, g["normalize"]) < TIGHT
+    out = unet_ref.layer_norm(g2_u("ln.x", (2, 64, 320)), sd, "g2.ln.norm")
+    assert max_rel_err(out, g["layernorm"]) < TIGHT
+
+
+def test_g4_schedules():
+    g = golden("g4_schedules")
+    tab = sampler_ref.ddpm_tables()
+    for k, v in tab.items():
+        assert torch.equal(v, g[k]), k
+    assert np.array_equal(sampler_ref.ddim_timesteps(50), np.arange(0, 1000, 20) + 1)
+    assert np.array_equal(sampler_ref.ddim_timesteps(10), np.arange(0, 1000, 100) + 1)
+    for Sn in (10, 50):
+        for eta in (0.0, 0.5):
+            d = sampler_ref.ddim_tables(tab["alphas_cumprod"], Sn, eta)
+            tag = f"S{Sn}_eta{eta}"
+            assert np.array_equal(d["timesteps"], g[f"{tag}.timesteps"].numpy())
+            assert np.array_equal(d["alphas"].astype(np.float64), g[f"{tag}.ddim_alphas"].numpy())
+            assert np.array_equal(d["alphas_prev"], g[f"{tag}.ddim_alphas_prev"].numpy())
+            assert np.array_equal(d["sqrt_one_minus_alphas"].astype(np.float64),
+                                  g[f"{tag}.ddim_sqrt_one_minus_alphas"].numpy())
+            np.testing.assert_allclose(d["sigmas"], g[f"{tag}.ddim_sigmas"].numpy(), rtol=1e-14, atol=0)
+
+
+def test_g5_sampler_kat():
+    g = golden("g5_sampler_kat")
+    tab = sampler_ref.ddpm_tables()
+    x, e_u, e_c, noise = g["x"], g["e_u"], g["e_c"], g["noise"]
+    e_t = sampler_ref.cfg_combine(e_u, e_c, 7.5)
+    for eta in (0.0, 0.5):
+        d = sampler_ref.ddim_tables(tab["alphas_cumprod"], 50, eta)
+        for index in (49, 20, 0):
+            xp, p0 = sampler_ref.ddim_update(x, e_t, d["alphas"][index], d["alphas_prev"][index],
+                                             d["sigmas"][index], d["sqrt_one_minus_alphas"][index], noise)
+            assert torch.equal(p0, g[f"eta{eta}.i{index}.pred_x0"])
+            assert torch.equal(xp, g[f"eta{eta}.i{index}.x_prev"])
+    d = sampler_ref.ddim_tables(tab["alphas_cumprod"], 50, 0.0)
+    for tidx in (36, 49):
+        out = sampler_ref.stochastic_encode(x, [tidx, tidx], d, noise)
+        assert torch.equal(out, g[f"stochastic_encode.t{tidx}"])
+    # q_sample (:3892) uses the 1000-step tables
+    t = torch.tensor([981, 1])
+    qs = (tab["sqrt_alphas_cumprod"][t].reshape(2, 1, 1, 1) * x +
+          tab["sqrt_one_minus_alphas_cumprod"][t].reshape(2, 1, 1, 1) * noise)
+    assert torch.equal(qs, g["q_sample.t981_1"])
+
+
+def _vae():
+    st = S.vae_decoder_structure(S.sd_v1_ddconfig(), 4)
+    return st, synth.synth_state_dict(S.vae_decoder_param_shapes(st), 0)
+
+
+def test_g8_vae_decode():
+    g = golden("g8_vae")
+    st, sd = _vae()
+    torch.set_num_threads(8)
+    raw = vae_ref.decode(sd, st, g["z"])
+    assert raw.shape == (1, 3, 256, 256)
+    assert max_rel_err(raw, g["dec_raw"]) < 1e-5
+    assert max_rel_err(vae_ref.decode_first_stage(sd, st, g["z"]), g["dec"]) < 1e-5

@@ -1,0 +1,176 @@
+/* libsdmi -- C ABI of the MI355X-native Stable-Diffusion-v1 denoising hot path.
+ *
+ * The reference (ShaShekhar/Stable-diffusion) is pure Python: the path it runs per DDIM step is
+ * nn.Module.forward calls, not an FFI.  This header is therefore the boundary a maintainer binds
+ * with ctypes underneath those modules; every entry point names the reference code it replaces
+ * (file = stable_diffusion.py unless stated).
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only; no torch types, no exceptions across the boundary;
+ *   - every function returns 0 on success or a negative code (SDMI_E*); the message for the calling
+ *     thread's last failure is returned by sdmi_last_error();
+ *   - all pointers named x/out/ctx/t/... are DEVICE pointers owned by the caller; the library
+ *     never frees them.  Weights are copied / repacked into handle-owned device memory;
+ *   - work is enqueued asynchronously on the HIP stream passed as `stream` (a hipStream_t cast to
+ *     void*; NULL = the default stream).  One handle must be used from one host thread at a time;
+ *     one handle per device.
+ *   - dtype codes: 0 = fp32, 1 = fp16, 2 = bf16.
+ */
+#ifndef SDMI_H
+#define SDMI_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDMI_VERSION 100          /* 0.1.0 */
+
+#define SDMI_DTYPE_F32 0
+#define SDMI_DTYPE_F16 1
+#define SDMI_DTYPE_BF16 2
+
+#define SDMI_OK 0
+#define SDMI_EINVAL (-22)
+#define SDMI_ENOMEM (-12)
+#define SDMI_EHIP (-5)
+#define SDMI_ENOENT (-2)
+#define SDMI_ESTATE (-1)
+
+int sdmi_version(void);
+const char* sdmi_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * UNet denoiser: replaces UNetModel.__init__ (:3263-3496) / UNetModel.forward (:3519-3552) and
+ * the DiffusionWrapper routing in front of it (:3646-3664).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sdmi_unet sdmi_unet;
+
+typedef struct sdmi_unet_cfg {
+  int in_channels;               /* 4, or 9 for the hybrid inpainting model            */
+  int model_channels;            /* 320                                                */
+  int out_channels;              /* 4                                                  */
+  int num_res_blocks;            /* 2                                                  */
+  int n_channel_mult;
+  int channel_mult[8];           /* 1,2,4,4                                            */
+  int n_attention_resolutions;
+  int attention_resolutions[8];  /* 4,2,1                                              */
+  int num_heads;                 /* 8, or -1 when num_head_channels is used            */
+  int num_head_channels;         /* -1, or channels per head                           */
+  int transformer_depth;         /* 1                                                  */
+  int context_dim;               /* 768                                                */
+  int legacy;                    /* the reference's `legacy` flag (:3352)              */
+  int compute_dtype;             /* activations / MFMA operand type; fp32 = parity mode */
+} sdmi_unet_cfg;
+
+int sdmi_unet_create(const sdmi_unet_cfg* cfg, sdmi_unet** out);
+/* Number of checkpoint tensors the configuration expects, and the i-th key / shape (relative to
+ * "model.diffusion_model.").  Replaces nn.Module.state_dict() introspection. */
+int sdmi_unet_num_weights(const sdmi_unet* u);
+int sdmi_unet_weight_info(const sdmi_unet* u, int index, const char** key, int64_t* shape4, int* ndim);
+/* Copy one checkpoint tensor (device pointer, fp32, reference layout: OIHW convs, (out,in)
+ * linears) into the handle.  Replaces load_state_dict (txt2img.py:213-220). */
+int sdmi_unet_set_weight(sdmi_unet* u, const char* key, const void* dev_ptr, const int64_t* shape,
+                         int ndim, int dtype, void* stream);
+/* Repack all weights to kernel layouts; fails with SDMI_ENOENT (message lists keys) if any is missing. */
+int sdmi_unet_finalize(sdmi_unet* u, void* stream);
+/* Project the text context once per prompt batch: K/V of every cross-attention block
+ * (CrossAttention.to_k/to_v, :2781-2782) are cached in the handle and reused by every step.
+ * ctx: fp32 [batch][ntok][context_dim]. */
+int sdmi_unet_set_context(sdmi_unet* u, const void* ctx, int batch, int ntok, void* stream);
+/* eps = UNet(cat([x] + concat, 1), t, context)   (:3519; hybrid cat :3656)
+ * x: fp32 NCHW [batch][c_x][h][w]; concat[i]: fp32 NCHW [batch][concat_channels[i]][h][w] (n_concat
+ * <= 2, c_x + sum = in_channels); t: int64 [batch]; out: fp32 NCHW [batch][out_channels][h][w].
+ * The context set by sdmi_unet_set_context must have the same batch. */
+int sdmi_unet_forward(sdmi_unet* u, const void* x, const void* const* concat, const int* concat_channels,
+                      int n_concat, const int64_t* t, void* out, int batch, int h, int w, void* stream);
+/* Bytes of device memory currently held (weights + caches + workspace). */
+int64_t sdmi_unet_device_bytes(const sdmi_unet* u);
+/* 1: replay the forward as a captured HIP graph when shapes and pointers repeat (default), 0: eager. */
+int sdmi_unet_set_graph_mode(sdmi_unet* u, int enable);
+void sdmi_unet_destroy(sdmi_unet* u);
+
+/* ------------------------------------------------------------------------------------------
+ * Sampler arithmetic: replaces DDIMSampler.p_sample_ddim :5344-5347, :5360-5375 (CFG combine +
+ * DDIM update), stochastic_encode :5378-5391 and DDPM.q_sample :3892-3895.  All fp32.
+ * ------------------------------------------------------------------------------------------ */
+/* eps: [e_uncond | e_cond] (2n floats) when cfg != 0, else n floats.  noise may be NULL (sigma 0).
+ * pred_x0 may be NULL. */
+int sdmi_ddim_step(const void* x, const void* eps, int cfg, float scale, float a_t, float a_prev,
+                   float sigma, float sqrt_one_minus_at, const void* noise, float temperature,
+                   void* x_prev, void* pred_x0, int64_t n, void* stream);
+/* out = ca * a + cb * b */
+int sdmi_axpby(const void* a, const void* b, float ca, float cb, void* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * VAE decoder: replaces LatentDiffusion.decode_first_stage :4293-4346 -> AutoencoderKL.decode
+ * :1416-1419 -> Decoder.forward :496-527.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sdmi_vae_decoder sdmi_vae_decoder;
+
+typedef struct sdmi_vae_cfg {
+  int z_channels;        /* 4   */
+  int embed_dim;         /* 4   */
+  int ch;                /* 128 (ddconfig 'ch_out') */
+  int out_ch;            /* 3   */
+  int n_ch_mult;
+  int ch_mult[8];        /* 1,2,4,4 */
+  int num_res_blocks;    /* 2   */
+  int compute_dtype;
+} sdmi_vae_cfg;
+
+int sdmi_vae_decoder_create(const sdmi_vae_cfg* cfg, sdmi_vae_decoder** out);
+int sdmi_vae_decoder_num_weights(const sdmi_vae_decoder* v);
+int sdmi_vae_decoder_weight_info(const sdmi_vae_decoder* v, int index, const char** key, int64_t* shape4, int* ndim);
+int sdmi_vae_decoder_set_weight(sdmi_vae_decoder* v, const char* key, const void* dev_ptr,
+                                const int64_t* shape, int ndim, int dtype, void* stream);
+int sdmi_vae_decoder_finalize(sdmi_vae_decoder* v, void* stream);
+/* out = Decoder(post_quant_conv(z * z_scale)); z fp32 NCHW [batch][z_channels][h][w],
+ * out fp32 NCHW [batch][out_ch][8h][8w].  z_scale = 1/scale_factor for decode_first_stage, 1 for
+ * AutoencoderKL.decode. */
+int sdmi_vae_decoder_forward(sdmi_vae_decoder* v, const void* z, float z_scale, void* out, int batch,
+                             int h, int w, void* stream);
+void sdmi_vae_decoder_destroy(sdmi_vae_decoder* v);
+/* out = clamp((x + 1) / 2, 0, 1)   (txt2img.py:307) */
+int sdmi_to_image(const void* x, void* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-op entry points (unit parity tests; also usable on their own).  Activations are NHWC /
+ * token-major in the given dtype unless stated.
+ * ------------------------------------------------------------------------------------------ */
+/* GroupNorm32 :2266 / Normalize :32 (+ optional SiLU); x1 may be NULL; scratch: fp32 device buffer
+ * of sdmi_groupnorm_scratch_bytes(batch, groups) bytes. */
+int64_t sdmi_groupnorm_scratch_bytes(int batch, int groups);
+int sdmi_groupnorm(const void* x0, int c0, const void* x1, int c1, int batch, int hw, int groups, float eps,
+                   const float* gamma, const float* beta, int silu, void* out, void* scratch, int dtype,
+                   void* stream);
+/* nn.LayerNorm (:2807-2809) over the last dim */
+int sdmi_layernorm(const void* x, void* out, const float* gamma, const float* beta, int rows, int d, float eps,
+                   int dtype, void* stream);
+/* Pack an OIHW (or (out,in) with taps = 1) fp32 weight to the conv/linear kernel layout. */
+int sdmi_pack_weight(const float* w, void* out, int out_ch, int in_ch, int taps, int dtype, void* stream);
+int sdmi_pack_geglu(const float* w, const float* b, void* wout, float* bout, int inner, int in_ch, int dtype,
+                    void* stream);
+/* nn.Conv2d 3x3 pad 1 / 1x1 / nn.Linear as implicit GEMM (Downsample :3095 stride 2, Upsample
+ * :3062-3064 up = 1, skip-concat :3545 via a1).  w from sdmi_pack_weight.  splits >= 1; partial =
+ * fp32 scratch of splits*M*N floats when splits > 1. */
+int sdmi_conv2d(const void* a0, int c0, const void* a1, int c1, const void* w, const float* bias,
+                const float* rowadd, const void* resid, int ldr, void* out, int ldo, int batch, int hin,
+                int win, int taps, int stride, int up, int n_out, int geglu, int splits, void* partial,
+                int dtype, void* stream);
+/* softmax(q k^T * scale) v per (batch, head)  (CrossAttention :2784-2796); impl 0 auto, 1 scalar */
+int sdmi_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
+                   int batch, int heads, int nq, int nk, int d, float scale, int dtype, int impl, void* stream);
+/* timestep_embedding :2212-2232 (fp32 out [batch][dim]) */
+int sdmi_timestep_embedding(const int64_t* t, float* out, int batch, int dim, float max_period, void* stream);
+/* y = act_out(act_in(x) W^T + b), fp32, small M (time_embed :3317-3322, emb_layers :3180-3183) */
+int sdmi_small_linear(const float* x, const float* w, const float* bias, float* y, int m, int k, int n,
+                      int act_in, int act_out, void* stream);
+/* dtype conversion helpers for tests */
+int sdmi_convert_from_f32(const float* x, void* out, int64_t n, int dtype, void* stream);
+int sdmi_convert_to_f32(const void* x, float* out, int64_t n, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDMI_H */

@@ -1,0 +1,104 @@
+// C-ABI glue for the per-op entry points of libsdmi (see include/sdmi.h) and the error channel.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/sdmi.h"
+#include "ops.h"
+
+static thread_local char g_err[2048] = "";
+
+void sdmi_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+
+int sdmi_version(void) { return SDMI_VERSION; }
+const char* sdmi_last_error(void) { return g_err; }
+
+int sdmi_ddim_step(const void* x, const void* eps, int cfg, float scale, float a_t, float a_prev, float sigma,
+                   float sqrt_one_minus_at, const void* noise, float temperature, void* x_prev, void* pred_x0,
+                   int64_t n, void* stream) {
+  return ddim_step((const float*)x, (const float*)eps, cfg, scale, a_t, a_prev, sigma, sqrt_one_minus_at,
+                   (const float*)noise, temperature, (float*)x_prev, (float*)pred_x0, n, (hipStream_t)stream);
+}
+
+int sdmi_axpby(const void* a, const void* b, float ca, float cb, void* out, int64_t n, void* stream) {
+  return axpby((const float*)a, (const float*)b, ca, cb, (float*)out, n, (hipStream_t)stream);
+}
+
+int sdmi_to_image(const void* x, void* out, int64_t n, void* stream) {
+  return to_image((const float*)x, (float*)out, n, (hipStream_t)stream);
+}
+
+int64_t sdmi_groupnorm_scratch_bytes(int batch, int groups) {
+  return (int64_t)groupnorm_scratch_floats(batch, 0, groups) * 4;
+}
+
+int sdmi_groupnorm(const void* x0, int c0, const void* x1, int c1, int batch, int hw, int groups, float eps,
+                   const float* gamma, const float* beta, int silu, void* out, void* scratch, int dtype,
+                   void* stream) {
+  GroupNormArgs a;
+  a.x0 = x0; a.c0 = c0; a.x1 = x1; a.c1 = c1; a.B = batch; a.HW = hw; a.groups = groups; a.eps = eps;
+  a.gamma = gamma; a.beta = beta; a.silu = silu; a.out = out; a.scratch = (float*)scratch; a.dtype = dtype;
+  return groupnorm(a, (hipStream_t)stream);
+}
+
+int sdmi_layernorm(const void* x, void* out, const float* gamma, const float* beta, int rows, int d, float eps,
+                   int dtype, void* stream) {
+  return layernorm(x, out, gamma, beta, rows, d, eps, dtype, (hipStream_t)stream);
+}
+
+int sdmi_pack_weight(const float* w, void* out, int out_ch, int in_ch, int taps, int dtype, void* stream) {
+  return pack_conv_weight(w, out, out_ch, in_ch, taps, dtype, (hipStream_t)stream);
+}
+
+int sdmi_pack_geglu(const float* w, const float* b, void* wout, float* bout, int inner, int in_ch, int dtype,
+                    void* stream) {
+  return pack_geglu_weight(w, b, wout, bout, inner, in_ch, dtype, (hipStream_t)stream);
+}
+
+int sdmi_conv2d(const void* a0, int c0, const void* a1, int c1, const void* w, const float* bias,
+                const float* rowadd, const void* resid, int ldr, void* out, int ldo, int batch, int hin, int win,
+                int taps, int stride, int up, int n_out, int geglu, int splits, void* partial, int dtype,
+                void* stream) {
+  ConvGemmArgs a;
+  a.a0 = a0; a.c0 = c0; a.a1 = a1; a.c1 = c1; a.w = w; a.bias = bias; a.rowadd = rowadd;
+  a.resid = resid; a.ldr = ldr; a.out = out; a.ldo = ldo; a.B = batch; a.Hin = hin; a.Win = win;
+  a.taps = taps; a.stride = stride; a.up = up; a.N = n_out; a.geglu = geglu; a.splits = splits;
+  a.partial = (float*)partial; a.dtype = dtype;
+  const int hup = up ? 2 * hin : hin, wup = up ? 2 * win : win;
+  if (taps == 9) { a.Ho = (hup + 2 - 3) / stride + 1; a.Wo = (wup + 2 - 3) / stride + 1; }
+  else { a.Ho = (hup - 1) / stride + 1; a.Wo = (wup - 1) / stride + 1; }
+  return conv_gemm(a, (hipStream_t)stream);
+}
+
+int sdmi_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
+                   int batch, int heads, int nq, int nk, int d, float scale, int dtype, int impl, void* stream) {
+  AttentionArgs a;
+  a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo;
+  a.B = batch; a.heads = heads; a.Nq = nq; a.Nk = nk; a.d = d; a.scale = scale; a.dtype = dtype; a.impl = impl;
+  return attention(a, (hipStream_t)stream);
+}
+
+int sdmi_timestep_embedding(const int64_t* t, float* out, int batch, int dim, float max_period, void* stream) {
+  return timestep_embedding(t, out, batch, dim, max_period, (hipStream_t)stream);
+}
+
+int sdmi_small_linear(const float* x, const float* w, const float* bias, float* y, int m, int k, int n, int act_in,
+                      int act_out, void* stream) {
+  return small_linear(x, w, bias, y, m, k, n, act_in, act_out, (hipStream_t)stream);
+}
+
+int sdmi_convert_from_f32(const float* x, void* out, int64_t n, int dtype, void* stream) {
+  return convert_f32(x, out, n, dtype, (hipStream_t)stream);
+}
+
+int sdmi_convert_to_f32(const void* x, float* out, int64_t n, int dtype, void* stream) {
+  return convert_to_f32(x, out, n, dtype, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,410 @@
+// Small and elementwise gfx950 kernels of the denoising path: timestep embedding, tiny-M linears,
+// the first and last convolutions (NCHW fp32 boundary <-> NHWC internal layout), the fused
+// classifier-free-guidance + DDIM update, row softmax, image post-scale and weight packing.
+#include "ops.h"
+#include <math.h>
+
+namespace {
+
+inline unsigned grid_for(size_t n, int block = 256, unsigned cap = 16384) {
+  size_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  return (unsigned)(g > cap ? cap : g);
+}
+
+// ---- timestep embedding ------------------------------------------------------------------------
+__global__ void timestep_embedding_kernel(const int64_t* t, float* out, int B, int dim, float neg_log_period) {
+  const int half = dim / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * half) return;
+  const int b = idx / half, k = idx - b * half;
+  // The exponent is formed in fp32 with the reference's operation order (scalar * k, then / half);
+  // exp / cos / sin are then evaluated in double and rounded once, i.e. correctly rounded fp32.
+  const float a = (neg_log_period * (float)k) / (float)half;
+  const float freq = (float)exp((double)a);
+  const float arg = (float)t[b] * freq;
+  out[(size_t)b * dim + k] = (float)cos((double)arg);
+  out[(size_t)b * dim + half + k] = (float)sin((double)arg);
+  if ((dim & 1) && k == 0) out[(size_t)b * dim + dim - 1] = 0.f;
+}
+
+// ---- tiny-M linear: one wave per output column, all rows at once ----------------------------------
+template <int MB>
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* x, const float* W, const float* bias,
+                                                           float* y, int M, int K, int N, int act_in, int act_out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int mb = blockIdx.y * MB;
+  if (n >= N) return;
+  float acc[MB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m) acc[m] = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = W[(size_t)n * K + k];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      if (mb + m < M) {
+        float xv = x[(size_t)(mb + m) * K + k];
+        if (act_in == 1) xv = silu_f(xv);
+        acc[m] += xv * w;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+    const float s = wave_sum(acc[m]);
+    if (lane == 0 && mb + m < M) {
+      float v = s + (bias ? bias[n] : 0.f);
+      if (act_out == 1) v = silu_f(v);
+      y[(size_t)(mb + m) * N + n] = v;
+    }
+  }
+}
+
+// ---- first convolution ---------------------------------------------------------------------------
+struct InConvParams {
+  const float* src[3]; int c[3]; int Cin;
+  const float* w; const float* bias; void* out;
+  int B, H, W, Cout;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void in_conv_kernel(InConvParams p) {
+  const size_t total = (size_t)p.B * p.H * p.W * p.Cout;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(idx % p.Cout);
+    const size_t pix = idx / p.Cout;
+    const int x = (int)(pix % p.W), y = (int)((pix / p.W) % p.H), b = (int)(pix / ((size_t)p.W * p.H));
+    float acc = p.bias[co];
+    for (int tap = 0; tap < 9; ++tap) {
+      const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+      if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) continue;
+      int cbase = 0;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        if (p.c[s] == 0) continue;
+        const float* sp = p.src[s] + ((size_t)b * p.c[s] * p.H + iy) * p.W + ix;
+        for (int ci = 0; ci < p.c[s]; ++ci)
+          acc += sp[(size_t)ci * p.H * p.W] * p.w[((size_t)tap * p.Cin + cbase + ci) * p.Cout + co];
+        cbase += p.c[s];
+      }
+    }
+    ((T*)p.out)[idx] = from_f32<T>(acc);
+  }
+}
+
+// ---- last convolution: one wave per output pixel ------------------------------------------------
+template <typename T, int COUT>
+__global__ __launch_bounds__(256) void out_conv_kernel(const T* x, const float* w, const float* bias, float* out,
+                                                       int B, int H, int W, int Cin) {
+  constexpr int EPV = VecOf<T>::N;
+  typedef typename VecOf<T>::type V;
+  const int lane = threadIdx.x & 63;
+  const size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= (size_t)B * H * W) return;
+  const int xx = (int)(pix % W), yy = (int)((pix / W) % H), b = (int)(pix / ((size_t)W * H));
+  float acc[COUT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+  const int nvec = Cin / EPV;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int iy = yy + tap / 3 - 1, ix = xx + tap % 3 - 1;
+    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+    const T* xp = x + (((size_t)b * H + iy) * W + ix) * Cin;
+    for (int v = lane; v < nvec; v += 64) {
+      const V xv = *reinterpret_cast<const V*>(xp + v * EPV);
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) {
+        const float* wp = w + ((size_t)o * 9 + tap) * Cin + v * EPV;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) acc[o] += to_f32<T>(xv[e]) * wp[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) {
+    const float s = wave_sum(acc[o]);
+    if (lane == 0) out[(((size_t)b * COUT + o) * H + yy) * W + xx] = s + bias[o];
+  }
+}
+
+__global__ void pointwise_nchw_kernel(const float* x, const float* w, const float* bias, float* out, int B,
+                                      int Cin, int Cout, int HW, float scale) {
+  const size_t total = (size_t)B * Cout * HW;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int px = (int)(idx % HW), co = (int)((idx / HW) % Cout), b = (int)(idx / ((size_t)HW * Cout));
+    float acc = bias[co];
+    for (int ci = 0; ci < Cin; ++ci) acc += w[co * Cin + ci] * (scale * x[((size_t)b * Cin + ci) * HW + px]);
+    out[idx] = acc;
+  }
+}
+
+// ---- sampler -----------------------------------------------------------------------------------
+__global__ void ddim_step_kernel(const float* x, const float* eps, int cfg, float scale, float sqrt_at,
+                                 float sqrt_aprev, float dir_coef, float sigma, float sqrt_1m_at,
+                                 const float* noise, float temperature, float* x_prev, float* pred_x0, int64_t n) {
+  // every product and sum is rounded separately, as the reference's elementwise torch ops are
+#pragma clang fp contract(off)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float e;
+    if (cfg) {
+      const float eu = eps[i], ec = eps[n + i];
+      e = eu + scale * (ec - eu);
+    } else {
+      e = eps[i];
+    }
+    const float xv = x[i];
+    // same operation order as the reference: (x - s*e) / sqrt(a_t); sqrt(a_prev)*p0 + dir*e + noise
+    const float p0 = (xv - sqrt_1m_at * e) / sqrt_at;
+    const float nz = noise ? sigma * noise[i] * temperature : 0.f;
+    const float xp = sqrt_aprev * p0 + dir_coef * e + nz;
+    if (pred_x0) pred_x0[i] = p0;
+    x_prev[i] = xp;
+  }
+}
+
+__global__ void axpby_kernel(const float* a, const float* b, float ca, float cb, float* out, int64_t n) {
+#pragma clang fp contract(off)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = ca * a[i] + cb * b[i];
+}
+
+__global__ void to_image_kernel(const float* x, float* out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = fminf(fmaxf((x[i] + 1.0f) / 2.0f, 0.f), 1.f);
+}
+
+// ---- row softmax (one block per row) ------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, T* p, int cols, float scale) {
+  __shared__ float red[4];
+  const float* row = s + (size_t)blockIdx.x * cols;
+  T* orow = p + (size_t)blockIdx.x * cols;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, row[c] * scale);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) red[wid] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float l = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) l += __expf(row[c] * scale - m);
+  l = wave_sum(l);
+  if (lane == 0) red[wid] = l;
+  __syncthreads();
+  l = red[0] + red[1] + red[2] + red[3];
+  const float inv = 1.0f / l;
+  for (int c = threadIdx.x; c < cols; c += 256) orow[c] = from_f32<T>(__expf(row[c] * scale - m) * inv);
+}
+
+// ---- packing --------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_conv_weight_kernel(const float* w, T* out, int O, int I, int taps) {
+  const size_t total = (size_t)O * I * taps;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx % I), tap = (int)((idx / I) % taps), o = (int)(idx / ((size_t)I * taps));
+    out[idx] = from_f32<T>(w[((size_t)o * I + i) * taps + tap]);
+  }
+}
+
+// packed row p: group = p/32, within = p%32; within<16 -> value row group*16+within, else gate row
+template <typename T>
+__global__ void pack_geglu_weight_kernel(const float* w, const float* b, T* wout, float* bout, int F, int I) {
+  const size_t total = (size_t)2 * F * I;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(idx % I), pr = (int)(idx / I);
+    const int grp = pr >> 5, within = pr & 31;
+    const int src = within < 16 ? grp * 16 + within : F + grp * 16 + (within - 16);
+    wout[idx] = from_f32<T>(w[(size_t)src * I + i]);
+    if (i == 0) bout[pr] = b[src];
+  }
+}
+
+__global__ void pack_inconv_weight_kernel(const float* w, float* out, int O, int I) {
+  const size_t total = (size_t)O * I * 9;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int o = (int)(idx % O), i = (int)((idx / O) % I), tap = (int)(idx / ((size_t)O * I));
+    out[idx] = w[((size_t)o * I + i) * 9 + tap];
+  }
+}
+
+template <typename T>
+__global__ void convert_f32_kernel(const float* x, T* out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = from_f32<T>(x[i]);
+}
+template <typename T>
+__global__ void convert_to_f32_kernel(const T* x, float* out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = to_f32<T>(x[i]);
+}
+
+}  // namespace
+
+int timestep_embedding(const int64_t* t, float* out, int B, int dim, float max_period, hipStream_t s) {
+  SDMI_REQUIRE(t && out && B > 0 && dim >= 2, "timestep_embedding: bad arguments");
+  const int n = B * (dim / 2);
+  const float neg_log_period = (float)(-log((double)max_period));
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, out, B, dim,
+                     neg_log_period);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int small_linear(const float* x, const float* W, const float* bias, float* y, int M, int K, int N, int act_in,
+                 int act_out, hipStream_t s) {
+  SDMI_REQUIRE(x && W && y && M > 0 && K > 0 && N > 0, "small_linear: bad arguments");
+  constexpr int MB = 8;
+  dim3 grid((N + 3) / 4, (M + MB - 1) / MB);
+  hipLaunchKernelGGL(small_linear_kernel<MB>, grid, dim3(256), 0, s, x, W, bias, y, M, K, N, act_in, act_out);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int in_conv(const InConvArgs& a, hipStream_t s) {
+  InConvParams p;
+  p.Cin = 0;
+  for (int i = 0; i < 3; ++i) {
+    p.src[i] = a.src[i]; p.c[i] = a.src[i] ? a.c[i] : 0; p.Cin += p.c[i];
+  }
+  SDMI_REQUIRE(a.src[0] && a.w && a.bias && a.out && p.Cin > 0 && p.Cin <= 64, "in_conv: bad arguments");
+  p.w = a.w; p.bias = a.bias; p.out = a.out; p.B = a.B; p.H = a.H; p.W = a.W; p.Cout = a.Cout;
+  const size_t total = (size_t)a.B * a.H * a.W * a.Cout;
+  SDMI_DISPATCH_DTYPE(a.dtype, T,
+                      hipLaunchKernelGGL(in_conv_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, p));
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+template <typename T>
+static int out_conv_t(const void* x, const float* w, const float* bias, float* out, int B, int H, int W,
+                      int Cin, int Cout, hipStream_t s) {
+  const size_t pix = (size_t)B * H * W;
+  dim3 grid((unsigned)((pix + 3) / 4));
+  if (Cout == 4)
+    hipLaunchKernelGGL((out_conv_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)x, w, bias, out, B, H, W, Cin);
+  else if (Cout == 3)
+    hipLaunchKernelGGL((out_conv_kernel<T, 3>), grid, dim3(256), 0, s, (const T*)x, w, bias, out, B, H, W, Cin);
+  else {
+    sdmi_set_error("out_conv: Cout=%d unsupported (3 or 4)", Cout);
+    return SDMI_EINVAL;
+  }
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int out_conv(const void* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cin,
+             int Cout, int dtype, hipStream_t s) {
+  SDMI_REQUIRE(x && w && bias && out, "out_conv: null pointer");
+  SDMI_REQUIRE(Cin % 8 == 0, "out_conv: Cin must be a multiple of 8");
+  SDMI_DISPATCH_DTYPE(dtype, T, return out_conv_t<T>(x, w, bias, out, B, H, W, Cin, Cout, s));
+  return SDMI_OK;
+}
+
+int pointwise_nchw(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout,
+                   int HW, float scale, hipStream_t s) {
+  SDMI_REQUIRE(x && w && bias && out, "pointwise_nchw: null pointer");
+  const size_t total = (size_t)B * Cout * HW;
+  hipLaunchKernelGGL(pointwise_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, w, bias, out, B, Cin, Cout,
+                     HW, scale);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int ddim_step(const float* x, const float* eps, int cfg, float scale, float a_t, float a_prev, float sigma,
+              float sqrt_1m_at, const float* noise, float temperature, float* x_prev, float* pred_x0, int64_t n,
+              hipStream_t s) {
+  SDMI_REQUIRE(x && eps && x_prev && n > 0, "ddim_step: bad arguments");
+  // scalar prefactors in fp32, exactly as the reference's fp32 tensors: sqrt(a_t), sqrt(a_prev),
+  // sqrt(1 - a_prev - sigma^2)
+  const float sqrt_at = sqrtf(a_t);
+  const float sqrt_aprev = sqrtf(a_prev);
+  const float dir_coef = sqrtf(1.0f - a_prev - sigma * sigma);
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for((size_t)n, 256, 2048)), dim3(256), 0, s, x, eps, cfg, scale,
+                     sqrt_at, sqrt_aprev, dir_coef, sigma, sqrt_1m_at, noise, temperature, x_prev, pred_x0, n);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int axpby(const float* a, const float* b, float ca, float cb, float* out, int64_t n, hipStream_t s) {
+  SDMI_REQUIRE(a && b && out && n > 0, "axpby: bad arguments");
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for((size_t)n, 256, 2048)), dim3(256), 0, s, a, b, ca, cb, out, n);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int to_image(const float* x, float* out, int64_t n, hipStream_t s) {
+  SDMI_REQUIRE(x && out && n > 0, "to_image: bad arguments");
+  hipLaunchKernelGGL(to_image_kernel, dim3(grid_for((size_t)n, 256, 4096)), dim3(256), 0, s, x, out, n);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int softmax_rows(const float* sc, void* p, int rows, int cols, float scale, int dtype, hipStream_t st) {
+  SDMI_REQUIRE(sc && p && rows > 0 && cols > 0, "softmax_rows: bad arguments");
+  SDMI_DISPATCH_DTYPE(dtype, T,
+                      hipLaunchKernelGGL(softmax_rows_kernel<T>, dim3(rows), dim3(256), 0, st, sc, (T*)p, cols, scale));
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int pack_conv_weight(const float* w, void* out, int O, int I, int taps, int dtype, hipStream_t s) {
+  SDMI_REQUIRE(w && out, "pack_conv_weight: null pointer");
+  const size_t total = (size_t)O * I * taps;
+  SDMI_DISPATCH_DTYPE(dtype, T,
+                      hipLaunchKernelGGL(pack_conv_weight_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, w,
+                                         (T*)out, O, I, taps));
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int pack_geglu_weight(const float* w, const float* b, void* wout, float* bout, int F, int I, int dtype,
+                      hipStream_t s) {
+  SDMI_REQUIRE(w && b && wout && bout && F % 16 == 0, "pack_geglu_weight: bad arguments");
+  const size_t total = (size_t)2 * F * I;
+  SDMI_DISPATCH_DTYPE(dtype, T,
+                      hipLaunchKernelGGL(pack_geglu_weight_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, w, b,
+                                         (T*)wout, bout, F, I));
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int pack_inconv_weight(const float* w, float* out, int O, int I, hipStream_t s) {
+  SDMI_REQUIRE(w && out, "pack_inconv_weight: null pointer");
+  hipLaunchKernelGGL(pack_inconv_weight_kernel, dim3(grid_for((size_t)O * I * 9)), dim3(256), 0, s, w, out, O, I);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int pack_outconv_weight(const float* w, float* out, int O, int I, hipStream_t s) {
+  SDMI_REQUIRE(w && out, "pack_outconv_weight: null pointer");
+  hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(grid_for((size_t)O * I * 9)), dim3(256), 0, s, w, out, O,
+                     I, 9);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int convert_f32(const float* x, void* out, int64_t n, int dtype, hipStream_t s) {
+  SDMI_REQUIRE(x && out && n > 0, "convert_f32: bad arguments");
+  SDMI_DISPATCH_DTYPE(dtype, T,
+                      hipLaunchKernelGGL(convert_f32_kernel<T>, dim3(grid_for((size_t)n)), dim3(256), 0, s, x,
+                                         (T*)out, n));
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int convert_to_f32(const void* x, float* out, int64_t n, int dtype, hipStream_t s) {
+  SDMI_REQUIRE(x && out && n > 0, "convert_to_f32: bad arguments");
+  SDMI_DISPATCH_DTYPE(dtype, T,
+                      hipLaunchKernelGGL(convert_to_f32_kernel<T>, dim3(grid_for((size_t)n)), dim3(256), 0, s,
+                                         (const T*)x, out, n));
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}

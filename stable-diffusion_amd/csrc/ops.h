@@ -1,0 +1,125 @@
+// Host-side launchers of the gfx950 kernels.  All of them enqueue on `stream` and return at once;
+// none allocates, frees or synchronises.  Activations are NHWC ("token-major": [rows][channels]).
+#pragma once
+#include "common.h"
+
+// ---- implicit-GEMM convolution / linear ---------------------------------------------------------
+// out[m][n] = epilogue( sum_k A(m,k) * Wp[n][k] ),  m = output pixel (b, oy, ox), n = out channel,
+// k = (tap, channel of the (possibly two-source) input).  Wp is the packed weight [N][K].
+struct ConvGemmArgs {
+  const void* a0 = nullptr;     // first input, NHWC [B][Hin][Win][c0]
+  const void* a1 = nullptr;     // optional second input (channel concat), NHWC [B][Hin][Win][c1]
+  int c0 = 0, c1 = 0;
+  const void* w = nullptr;      // packed weights [N][taps*(c0+c1)], element type = dtype
+  void* out = nullptr;          // [M][ldo] (dtype)
+  int ldo = 0;
+  const float* bias = nullptr;  // [N] fp32 or null
+  const float* rowadd = nullptr;// [B][ldra] fp32 or null: added per sample (time-embedding projection)
+  int ldra = 0;                 // row stride of rowadd (0 = N)
+  int out_f32 = 0;              // 1: store fp32 regardless of dtype (attention scores)
+  const void* resid = nullptr;  // [M][ldr] (dtype) or null; may alias out
+  int ldr = 0;
+  int B = 1, Hin = 1, Win = 1;  // input spatial size (before the optional x2 nearest upsample)
+  int Ho = 1, Wo = 1;           // output spatial size
+  int taps = 1;                 // 1 (pointwise / linear) or 9 (3x3, pad 1)
+  int stride = 1;               // 1 or 2
+  int up = 0;                   // 1: input is nearest-upsampled x2 on the fly
+  int N = 0;                    // output channels (rows of Wp)
+  int geglu = 0;                // 1: Wp rows interleave (value,gate) 16-row groups; out has N/2 columns
+  int dtype = SDMI_F16;
+  // split-K: when splits > 1 the kernel writes fp32 partial sums to `partial` ([splits][M][N]) and
+  // conv_gemm() launches the reduction+epilogue kernel itself.
+  int splits = 1;
+  float* partial = nullptr;
+};
+int conv_gemm(const ConvGemmArgs& a, hipStream_t stream);
+int conv_gemm_init();   // one-time kernel attribute setup; call outside stream capture
+// smallest split count worth using for this shape on a 256-CU part (1 = no split)
+int conv_gemm_pick_splits(int M, int N, int K, int dtype);
+
+// ---- normalisation ---------------------------------------------------------------------------
+struct GroupNormArgs {
+  const void* x0 = nullptr;     // NHWC [B][HW][c0]
+  const void* x1 = nullptr;     // optional second source (channel concat) [B][HW][c1]
+  int c0 = 0, c1 = 0;
+  int B = 1, HW = 1;
+  int groups = 32;
+  float eps = 1e-5f;
+  const float* gamma = nullptr; // [C] fp32
+  const float* beta = nullptr;  // [C] fp32
+  int silu = 0;
+  void* out = nullptr;          // NHWC [B][HW][C]
+  float* scratch = nullptr;     // >= groupnorm_scratch_floats(B, HW) floats
+  int dtype = SDMI_F16;
+};
+size_t groupnorm_scratch_floats(int B, int HW, int groups);
+int groupnorm(const GroupNormArgs& a, hipStream_t stream);
+
+int layernorm(const void* x, void* out, const float* gamma, const float* beta, int rows, int d,
+              float eps, int dtype, hipStream_t stream);
+
+// ---- attention -------------------------------------------------------------------------------
+struct AttentionArgs {
+  const void* q = nullptr; int ldq = 0;   // [B][Nq][ldq], head h at columns [h*d, (h+1)*d)
+  const void* k = nullptr; int ldk = 0;   // [B][Nk][ldk]
+  const void* v = nullptr; int ldv = 0;   // [B][Nk][ldv]
+  void* out = nullptr;     int ldo = 0;   // [B][Nq][ldo]
+  int B = 1, heads = 1, Nq = 0, Nk = 0, d = 0;
+  float scale = 1.f;
+  int dtype = SDMI_F16;
+  int impl = 0;                           // 0 = auto, 1 = force the scalar (fp32-math) kernel
+};
+int attention(const AttentionArgs& a, hipStream_t stream);
+
+// ---- small / elementwise ---------------------------------------------------------------------
+// emb[b][:] = [cos(t*f) | sin(t*f)], f_k = exp(-ln(max_period) k / half)            (fp32 out)
+int timestep_embedding(const int64_t* t, float* out, int B, int dim, float max_period, hipStream_t s);
+// y[m][n] = act_out( sum_k act_in(x[m][k]) * W[n][k] + b[n] ), fp32 everywhere, tiny M
+// act: 0 none, 1 SiLU
+int small_linear(const float* x, const float* W, const float* bias, float* y, int M, int K, int N,
+                 int act_in, int act_out, hipStream_t s);
+
+// first convolution: NCHW fp32 sources (channel-concatenated) -> NHWC dtype, 3x3 pad 1 stride 1
+struct InConvArgs {
+  const float* src[3] = {nullptr, nullptr, nullptr};   // each [B][c_i][H][W]
+  int c[3] = {0, 0, 0};
+  const float* w = nullptr;      // packed [9*Cin][Cout] fp32 (tap-major, then input channel)
+  const float* bias = nullptr;   // [Cout]
+  void* out = nullptr;           // NHWC [B][H][W][Cout]
+  int B = 1, H = 1, W = 1, Cout = 0;
+  int dtype = SDMI_F16;
+};
+int in_conv(const InConvArgs& a, hipStream_t s);
+// last convolution: NHWC dtype -> NCHW fp32, 3x3 pad 1, Cout <= 4
+int out_conv(const void* x, const float* w /*[Cout][9][Cin] fp32*/, const float* bias, float* out,
+             int B, int H, int W, int Cin, int Cout, int dtype, hipStream_t s);
+// pointwise NCHW fp32 conv with tiny channel counts: out = W*(scale*x) + b  (post_quant_conv)
+int pointwise_nchw(const float* x, const float* w, const float* bias, float* out, int B, int Cin,
+                   int Cout, int HW, float scale, hipStream_t s);
+
+// fused classifier-free guidance + DDIM update (all fp32, NCHW or any layout: purely elementwise)
+//   e = e_u + scale (e_c - e_u);  pred_x0 = (x - sqrt_1m_at e)/sqrt(a_t);
+//   x_prev = sqrt(a_prev) pred_x0 + sqrt(1 - a_prev - sigma^2) e + sigma * noise * temperature
+// eps points at [e_u | e_c] (each n elements) when cfg != 0, else at e (n elements).
+int ddim_step(const float* x, const float* eps, int cfg, float scale, float a_t, float a_prev,
+              float sigma, float sqrt_1m_at, const float* noise, float temperature, float* x_prev,
+              float* pred_x0, int64_t n, hipStream_t s);
+// out = ca * a + cb * b   (stochastic_encode / q_sample with per-call scalars; fp32)
+int axpby(const float* a, const float* b, float ca, float cb, float* out, int64_t n, hipStream_t s);
+// row softmax over fp32 scores -> dtype probabilities (VAE mid-block attention, two-pass path)
+int softmax_rows(const float* s, void* p, int rows, int cols, float scale, int dtype, hipStream_t st);
+// out[i] = clamp((x[i]+1)/2, 0, 1)
+int to_image(const float* x, float* out, int64_t n, hipStream_t s);
+
+// ---- weight packing (device side, run once at load) ---------------------------------------------
+// OIHW fp32 -> [O][tap][I] dtype (tap = ky*3+kx); also serves (O,I) linear weights with taps = 1
+int pack_conv_weight(const float* w, void* out, int O, int I, int taps, int dtype, hipStream_t s);
+// rows of a (2F, I) fp32 matrix -> (value,gate)-interleaved 16-row groups; same permutation on bias
+int pack_geglu_weight(const float* w, const float* b, void* wout, float* bout, int F, int I, int dtype,
+                      hipStream_t s);
+// OIHW fp32 -> [tap][I][O] fp32 for in_conv
+int pack_inconv_weight(const float* w, float* out, int O, int I, hipStream_t s);
+// OIHW fp32 -> [O][tap][I] fp32 for out_conv
+int pack_outconv_weight(const float* w, float* out, int O, int I, hipStream_t s);
+int convert_f32(const float* x, void* out, int64_t n, int dtype, hipStream_t s);
+int convert_to_f32(const void* x, float* out, int64_t n, int dtype, hipStream_t s);

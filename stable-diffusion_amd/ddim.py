@@ -1,0 +1,254 @@
+"""DDIMSampler with the reference's interface (stable_diffusion.py:5141-5412) on top of libsdmi.
+
+The schedule tables are computed on the host with the same numpy/torch mixed-precision arithmetic as
+the reference; each step is one UNet launch sequence (a HIP-graph replay once pointers repeat) and
+one fused classifier-free-guidance + DDIM-update kernel.  Buffers are allocated once per call so
+device pointers stay stable across the S steps.
+
+Conditioning contract (the one call sequence of the reference that runs): ``conditioning`` is
+``cat([uncond, cond])`` on the batch axis (uncond first, matching ``.chunk(2)`` at :5346) and
+``unconditional_conditioning`` is merely truthy.
+"""
+import numpy as np
+import torch
+from tqdm import tqdm
+
+from . import ops
+
+
+def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
+    """stable_diffusion.py:5141-5153."""
+    if ddim_discr_method == "uniform":
+        c = num_ddpm_timesteps // num_ddim_timesteps
+        ddim_timesteps = np.asarray(list(range(0, num_ddpm_timesteps, c)))
+    elif ddim_discr_method == "quad":
+        ddim_timesteps = ((np.linspace(0, np.sqrt(num_ddpm_timesteps * 0.8), num_ddim_timesteps)) ** 2).astype(int)
+    else:
+        raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
+    steps_out = ddim_timesteps + 1
+    if verbose:
+        print(f"Selected timesteps for ddim sampler: {steps_out}")
+    return steps_out
+
+
+def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
+    """stable_diffusion.py:5155-5165; ``alphacums`` is the fp32 CPU tensor, so ``alphas`` stays an fp32
+    tensor, ``alphas_prev`` a float64 ndarray of fp32 values and ``sigmas`` a float64 tensor in which
+    1/(1-alphas) was rounded to fp32 (ndarray / tensor runs as reciprocal(tensor) * ndarray)."""
+    alphas = alphacums[ddim_timesteps]
+    alphas_prev = np.asarray([float(alphacums[0])] + alphacums[ddim_timesteps[:-1]].tolist())
+    recip = torch.reciprocal(1 - alphas).double()
+    sigmas = eta * torch.sqrt(recip * torch.from_numpy(1 - alphas_prev) * (1 - alphas.double() / torch.from_numpy(alphas_prev)))
+    if verbose:
+        print(f"Selected alphas for ddim sampler: a_t: {alphas}; a_(t-1): {alphas_prev}")
+        print(f"For the chosen value of eta, which is {eta}, "
+              f"this results in the following sigma_t schedule for ddim sampler {sigmas}")
+    return sigmas, alphas, alphas_prev
+
+
+class DDIMSampler(object):
+    def __init__(self, model, schedule="linear", **kwargs):
+        super().__init__()
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+
+    def register_buffer(self, name, attr):
+        setattr(self, name, attr)
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discr_method=ddim_discretize,
+                                                  num_ddim_timesteps=ddim_num_steps,
+                                                  num_ddpm_timesteps=self.ddpm_num_timesteps, verbose=verbose)
+        alphas_cumprod = self.model.alphas_cumprod.cpu()
+        assert alphas_cumprod.shape[0] == self.ddpm_num_timesteps, 'alphas have to be defined for each timestep'
+        f32 = lambda x: x.clone().detach().to(torch.float32).cpu()
+        self.register_buffer('betas', f32(self.model.betas))
+        self.register_buffer('alphas_cumprod', f32(alphas_cumprod))
+        self.register_buffer('alphas_cumprod_prev', f32(self.model.alphas_cumprod_prev))
+        self.register_buffer('sqrt_alphas_cumprod', f32(np.sqrt(alphas_cumprod)))
+        self.register_buffer('sqrt_one_minus_alphas_cumprod', f32(np.sqrt(1. - alphas_cumprod)))
+        self.register_buffer('log_one_minus_alphas_cumprod', f32(np.log(1. - alphas_cumprod)))
+        self.register_buffer('sqrt_recip_alphas_cumprod', f32(np.sqrt(1. / alphas_cumprod)))
+        self.register_buffer('sqrt_recipm1_alphas_cumprod', f32(np.sqrt(1. / alphas_cumprod - 1)))
+        ddim_sigmas, ddim_alphas, ddim_alphas_prev = make_ddim_sampling_parameters(
+            alphacums=alphas_cumprod, ddim_timesteps=self.ddim_timesteps, eta=ddim_eta, verbose=verbose)
+        self.register_buffer('ddim_sigmas', ddim_sigmas)
+        self.register_buffer('ddim_alphas', ddim_alphas)
+        self.register_buffer('ddim_alphas_prev', ddim_alphas_prev)
+        self.register_buffer('ddim_sqrt_one_minus_alphas', np.sqrt(1. - ddim_alphas))
+        sigmas_for_original_sampling_steps = ddim_eta * torch.sqrt(
+            (1 - self.alphas_cumprod_prev) / (1 - self.alphas_cumprod) * (
+                1 - self.alphas_cumprod / self.alphas_cumprod_prev))
+        self.register_buffer('ddim_sigmas_for_original_num_steps', sigmas_for_original_sampling_steps)
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None,
+               img_callback=None, quantize_x0=False, eta=0., mask=None, x0=None, temperature=1.,
+               noise_dropout=0., score_corrector=None, corrector_kwargs=None, verbose=True, x_T=None,
+               log_every_t=100, unconditional_guidance_scale=1., unconditional_conditioning=None, **kwargs):
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        C, H, W = shape
+        size = (batch_size, C, H, W)
+        if verbose:
+            print(f'Data shape for DDIM sampling is {size}, eta {eta}')
+        return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback,
+                                  quantize_denoised=quantize_x0, mask=mask, x0=x0, ddim_use_original_steps=False,
+                                  noise_dropout=noise_dropout, temperature=temperature,
+                                  score_corrector=score_corrector, corrector_kwargs=corrector_kwargs, x_T=x_T,
+                                  log_every_t=log_every_t,
+                                  unconditional_guidance_scale=unconditional_guidance_scale,
+                                  unconditional_conditioning=unconditional_conditioning, verbose=verbose,
+                                  noise_fn=kwargs.get("noise_fn"))
+
+    @torch.no_grad()
+    def ddim_sampling(self, conditioning, shape, x_T=None, ddim_use_original_steps=False, callback=None,
+                      timesteps=None, quantize_denoised=False, mask=None, x0=None, img_callback=None,
+                      log_every_t=100, temperature=1., noise_dropout=0., score_corrector=None,
+                      corrector_kwargs=None, unconditional_guidance_scale=1., unconditional_conditioning=None,
+                      verbose=True, noise_fn=None):
+        device = self.model.device
+        b = shape[0]
+        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device, torch.float32)
+        if timesteps is None:
+            timesteps = self.ddpm_num_timesteps if ddim_use_original_steps else self.ddim_timesteps
+        elif timesteps is not None and not ddim_use_original_steps:
+            subset_end = int(min(timesteps / self.ddim_timesteps.shape[0], 1) * self.ddim_timesteps.shape[0]) - 1
+            timesteps = self.ddim_timesteps[:subset_end]
+        u_cond = unconditional_conditioning is not None and unconditional_guidance_scale != 1.
+        cond = conditioning
+        intermediates = {'x_inter': [img], 'pred_x0': [img]}
+        time_range = reversed(range(0, timesteps)) if ddim_use_original_steps else np.flip(timesteps)
+        total_steps = timesteps if ddim_use_original_steps else timesteps.shape[0]
+        if verbose:
+            print(f"Running DDIM Sampling with {total_steps} timesteps")
+        iterator = tqdm(time_range, desc='DDIM Sampler', total=total_steps, disable=not verbose)
+        st = self._StepState(self, img, u_cond)
+        for i, step in enumerate(iterator):
+            index = total_steps - i - 1
+            if mask is not None:
+                assert x0 is not None
+                ts = torch.full((b,), int(step), dtype=torch.long)
+                img_orig = self.model.q_sample(x0, ts)
+                m = mask.to(device, torch.float32)
+                st.set_x(img_orig * m + (1. - m) * st.x())
+            pred_x0 = st.step(cond, int(step), index, use_original_steps=ddim_use_original_steps,
+                              quantize_denoised=quantize_denoised, temperature=temperature,
+                              noise_dropout=noise_dropout, score_corrector=score_corrector,
+                              unconditional_guidance_scale=unconditional_guidance_scale, noise_fn=noise_fn,
+                              want_pred_x0=img_callback is not None)
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(pred_x0, i)
+        return st.x().clone(), intermediates
+
+    class _StepState:
+        """Persistent device buffers for a sampling loop: the (possibly doubled) UNet input, the
+        timestep vector and the eps output keep their addresses from step to step."""
+
+        def __init__(self, sampler, img, doubled):
+            self.s = sampler
+            self.b = img.shape[0]
+            self.doubled = doubled
+            dev = sampler.model.device
+            reps = 2 if doubled else 1
+            self.x_in = img.to(dev, torch.float32).repeat(reps, 1, 1, 1).contiguous()
+            self.t_in = torch.zeros((reps * self.b,), dtype=torch.int64, device=dev)
+            self.eps = torch.empty_like(self.x_in)
+            self.x_next = torch.empty_like(self.x_in[:self.b])
+            self.pred = torch.empty_like(self.x_next)
+            self.t_val = None
+
+        def x(self):
+            return self.x_in[:self.b]
+
+        def set_x(self, x):
+            self.x_in.view(-1, self.b, *self.x_in.shape[1:])[:] = x
+
+        def step(self, cond, t_value, index, use_original_steps=False, quantize_denoised=False, temperature=1.,
+                 noise_dropout=0., score_corrector=None, unconditional_guidance_scale=1., noise_fn=None,
+                 want_pred_x0=True):
+            s = self.s
+            if quantize_denoised or score_corrector is not None or noise_dropout > 0.:
+                raise NotImplementedError("quantize_denoised / score_corrector / noise_dropout are not on the "
+                                          "MI355X sampling path (no reference script uses them)")
+            if self.t_val != t_value:
+                self.t_in.fill_(t_value)
+                self.t_val = t_value
+            s.model.apply_model(self.x_in, self.t_in, cond, out=self.eps)
+            a_t, a_prev, sigma_t, sqrt_1m = s._scalars(index, use_original_steps)
+            noise = None
+            if sigma_t != 0.:
+                shape = self.x_next.shape
+                noise = noise_fn(shape) if noise_fn is not None else torch.randn(shape, device=self.x_next.device)
+                noise = noise.to(self.x_next.device, torch.float32).contiguous()
+            from ._lib import lib, check, ptr, stream_ptr
+            check(lib().sdmi_ddim_step(ptr(self.x_in), ptr(self.eps), 1 if self.doubled else 0,
+                                       float(unconditional_guidance_scale), a_t, a_prev, sigma_t, sqrt_1m, ptr(noise),
+                                       float(temperature), ptr(self.x_next), ptr(self.pred) if want_pred_x0 else None,
+                                       self.x_next.numel(), stream_ptr()), "ddim_step")
+            self.set_x(self.x_next)
+            return self.pred if want_pred_x0 else None
+
+    def _scalars(self, index, use_original_steps):
+        """The four per-step scalars of p_sample_ddim (:5355-5363), as python floats of fp32 values."""
+        if use_original_steps:
+            alphas, alphas_prev = self.model.alphas_cumprod, self.model.alphas_cumprod_prev
+            sqrt_1m, sigmas = self.model.sqrt_one_minus_alphas_cumprod, self.ddim_sigmas_for_original_num_steps
+        else:
+            alphas, alphas_prev = self.ddim_alphas, self.ddim_alphas_prev
+            sqrt_1m, sigmas = self.ddim_sqrt_one_minus_alphas, self.ddim_sigmas
+        f32 = lambda v: float(np.float32(float(v)))      # torch.full(..., value) materialises fp32
+        return f32(alphas[index]), f32(alphas_prev[index]), f32(sigmas[index]), f32(sqrt_1m[index])
+
+    @torch.no_grad()
+    def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
+                      temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
+                      unconditional_guidance_scale=1., unconditional_conditioning=True, noise=None):
+        """One step with the reference's signature; returns (x_prev, pred_x0)."""
+        doubled = bool(unconditional_conditioning) and unconditional_guidance_scale != 1.
+        st = self._StepState(self, x, doubled)
+        t_value = int(t[0])
+        pred = st.step(c, t_value, index, use_original_steps=use_original_steps,
+                       quantize_denoised=quantize_denoised, temperature=temperature, noise_dropout=noise_dropout,
+                       score_corrector=score_corrector, unconditional_guidance_scale=unconditional_guidance_scale,
+                       noise_fn=(lambda shape: noise) if noise is not None else None)
+        return st.x().clone(), pred.clone()
+
+    @torch.no_grad()
+    def stochastic_encode(self, x0, t, use_original_steps=False, noise=None):
+        """sqrt(a[t]) * x0 + sqrt(1-a[t]) * noise with the ddim tables (:5378-5391); t indexes them."""
+        if use_original_steps:
+            sqrt_a, sqrt_1m = self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod
+        else:
+            sqrt_a, sqrt_1m = torch.sqrt(self.ddim_alphas), self.ddim_sqrt_one_minus_alphas
+        dev = self.model.device
+        x0 = x0.to(dev, torch.float32).contiguous()
+        if noise is None:
+            noise = torch.randn_like(x0)
+        noise = noise.to(dev, torch.float32).contiguous()
+        t = torch.as_tensor(t).cpu().long().reshape(-1)
+        out = torch.empty_like(x0)
+        for i in range(x0.shape[0]):
+            out[i] = ops.axpby(x0[i], noise[i], float(sqrt_a[t[i]]), float(sqrt_1m[t[i]]))
+        return out
+
+    @torch.no_grad()
+    def decode(self, x_latent, cond, t_start, unconditional_guidance_scale=1.0, unconditional_conditioning=None,
+               use_original_steps=False, verbose=True):
+        """img2img denoising loop (:5394-5412)."""
+        timesteps = np.arange(self.ddpm_num_timesteps) if use_original_steps else self.ddim_timesteps
+        timesteps = timesteps[:t_start]
+        time_range = np.flip(timesteps)
+        total_steps = timesteps.shape[0]
+        if verbose:
+            print(f"Running DDIM Sampling with {total_steps} timesteps")
+        doubled = bool(unconditional_conditioning is not None and unconditional_conditioning is not False) \
+            and unconditional_guidance_scale != 1.
+        st = self._StepState(self, x_latent, doubled)
+        for i, step in enumerate(tqdm(time_range, desc='Decoding image', total=total_steps, disable=not verbose)):
+            index = total_steps - i - 1
+            st.step(cond, int(step), index, use_original_steps=use_original_steps,
+                    unconditional_guidance_scale=unconditional_guidance_scale, want_pred_x0=False)
+        return st.x().clone()

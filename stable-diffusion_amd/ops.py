@@ -1,0 +1,158 @@
+"""Per-op Python wrappers over the C ABI (device tensors in, device tensors out).
+
+Activations are NHWC / token-major in the compute dtype.  Used by the unit parity tests and
+usable on their own; every call goes through libsdmi.so and raises if it is missing.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr, dtype_code, torch_dtype
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous()
+    return t
+
+
+def convert(x_f32, dtype):
+    x_f32 = _f32(x_f32.contiguous())
+    out = torch.empty(x_f32.shape, dtype=torch_dtype(dtype), device=x_f32.device)
+    check(_lib.lib().sdmi_convert_from_f32(ptr(x_f32), ptr(out), x_f32.numel(), dtype_code(dtype), stream_ptr()),
+          "convert_from_f32")
+    return out
+
+
+def to_f32(x):
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(_lib.lib().sdmi_convert_to_f32(ptr(x), ptr(out), x.numel(), dtype_code(x.dtype), stream_ptr()),
+          "convert_to_f32")
+    return out
+
+
+def pack_weight(w_f32, dtype):
+    """(O,I,kh,kw) or (O,I) fp32 -> packed [O][taps*I] in dtype."""
+    w_f32 = _f32(w_f32.contiguous())
+    O, I = w_f32.shape[0], w_f32.shape[1]
+    taps = 1 if w_f32.dim() == 2 else w_f32.shape[2] * w_f32.shape[3]
+    out = torch.empty((O, taps * I), dtype=torch_dtype(dtype), device=w_f32.device)
+    check(_lib.lib().sdmi_pack_weight(ptr(w_f32), ptr(out), O, I, taps, dtype_code(dtype), stream_ptr()),
+          "pack_weight")
+    return out
+
+
+def pack_geglu(w_f32, b_f32, dtype):
+    w_f32, b_f32 = _f32(w_f32.contiguous()), _f32(b_f32.contiguous())
+    F2, I = w_f32.shape
+    wout = torch.empty((F2, I), dtype=torch_dtype(dtype), device=w_f32.device)
+    bout = torch.empty((F2,), dtype=torch.float32, device=w_f32.device)
+    check(_lib.lib().sdmi_pack_geglu(ptr(w_f32), ptr(b_f32), ptr(wout), ptr(bout), F2 // 2, I, dtype_code(dtype),
+                                     stream_ptr()), "pack_geglu")
+    return wout, bout
+
+
+def conv2d(x, w_packed, bias=None, *, taps=9, stride=1, up=False, x1=None, rowadd=None, resid=None,
+           geglu=False, splits=1, n_out=None):
+    """x: NHWC (B,H,W,C0) [+ x1 (B,H,W,C1)] -> NHWC (B,Ho,Wo,N) (N/2 with geglu)."""
+    B, H, W, C0 = x.shape
+    C1 = x1.shape[3] if x1 is not None else 0
+    N = n_out if n_out is not None else w_packed.shape[0]
+    Hup, Wup = (2 * H, 2 * W) if up else (H, W)
+    if taps == 9:
+        Ho, Wo = (Hup + 2 - 3) // stride + 1, (Wup + 2 - 3) // stride + 1
+    else:
+        Ho, Wo = (Hup - 1) // stride + 1, (Wup - 1) // stride + 1
+    No = N // 2 if geglu else N
+    out = torch.empty((B, Ho, Wo, No), dtype=x.dtype, device=x.device)
+    partial = None
+    if splits > 1:
+        partial = torch.empty((splits, B * Ho * Wo, N), dtype=torch.float32, device=x.device)
+    check(_lib.lib().sdmi_conv2d(ptr(x), C0, ptr(x1), C1, ptr(w_packed), ptr(bias), ptr(rowadd), ptr(resid),
+                                 resid.shape[-1] if resid is not None else 0, ptr(out), No, B, H, W, taps, stride,
+                                 1 if up else 0, N, 1 if geglu else 0, splits, ptr(partial), dtype_code(x.dtype),
+                                 stream_ptr()), "conv2d")
+    return out
+
+
+def linear(x, w_packed, bias=None, resid=None, geglu=False, splits=1):
+    """x: (rows, K) -> (rows, N)."""
+    rows, K = x.shape
+    y = conv2d(x.view(1, 1, rows, K), w_packed, bias, taps=1, resid=resid, geglu=geglu, splits=splits)
+    return y.view(rows, -1)
+
+
+def groupnorm(x, gamma, beta, eps, silu=False, x1=None, groups=32):
+    """x: NHWC (B,H,W,C0) [+ x1] -> NHWC (B,H,W,C0+C1)."""
+    B, H, W, C0 = x.shape
+    C1 = x1.shape[3] if x1 is not None else 0
+    out = torch.empty((B, H, W, C0 + C1), dtype=x.dtype, device=x.device)
+    nbytes = _lib.lib().sdmi_groupnorm_scratch_bytes(B, groups)
+    scratch = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+    check(_lib.lib().sdmi_groupnorm(ptr(x), C0, ptr(x1), C1, B, H * W, groups, eps, ptr(_f32(gamma)), ptr(_f32(beta)),
+                                    1 if silu else 0, ptr(out), ptr(scratch), dtype_code(x.dtype), stream_ptr()),
+          "groupnorm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    rows, d = x.shape
+    out = torch.empty_like(x)
+    check(_lib.lib().sdmi_layernorm(ptr(x), ptr(out), ptr(_f32(gamma)), ptr(_f32(beta)), rows, d, eps,
+                                    dtype_code(x.dtype), stream_ptr()), "layernorm")
+    return out
+
+
+def attention(q, k, v, heads, scale=None, impl=0):
+    """q: (B,Nq,heads*d), k/v: (B,Nk,heads*d) (may be strided views over the last dim) -> (B,Nq,heads*d)."""
+    B, Nq, C = q.shape
+    Nk = k.shape[1]
+    d = C // heads
+    scale = d ** -0.5 if scale is None else scale
+    out = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
+    for t in (q, k, v):
+        assert t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1)
+    check(_lib.lib().sdmi_attention(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(out), C, B,
+                                    heads, Nq, Nk, d, scale, dtype_code(q.dtype), impl, stream_ptr()), "attention")
+    return out
+
+
+def timestep_embedding(t, dim, max_period=10000.0):
+    assert t.dtype == torch.int64 and t.is_cuda
+    out = torch.empty((t.shape[0], dim), dtype=torch.float32, device=t.device)
+    check(_lib.lib().sdmi_timestep_embedding(ptr(t), ptr(out), t.shape[0], dim, max_period, stream_ptr()),
+          "timestep_embedding")
+    return out
+
+
+def small_linear(x, w, b=None, act_in=0, act_out=0):
+    x, w = _f32(x.contiguous()), _f32(w.contiguous())
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    check(_lib.lib().sdmi_small_linear(ptr(x), ptr(w), ptr(b), ptr(y), M, K, N, act_in, act_out, stream_ptr()),
+          "small_linear")
+    return y
+
+
+def ddim_step(x, eps, cfg, scale, a_t, a_prev, sigma, sqrt_1m_at, noise=None, temperature=1.0, want_pred_x0=True):
+    x, eps = _f32(x), _f32(eps)
+    x_prev = torch.empty_like(x)
+    pred = torch.empty_like(x) if want_pred_x0 else None
+    check(_lib.lib().sdmi_ddim_step(ptr(x), ptr(eps), 1 if cfg else 0, float(scale), float(a_t), float(a_prev),
+                                    float(sigma), float(sqrt_1m_at), ptr(noise), float(temperature), ptr(x_prev),
+                                    ptr(pred), x.numel(), stream_ptr()), "ddim_step")
+    return x_prev, pred
+
+
+def axpby(a, b, ca, cb):
+    a, b = _f32(a), _f32(b)
+    out = torch.empty_like(a)
+    check(_lib.lib().sdmi_axpby(ptr(a), ptr(b), float(ca), float(cb), ptr(out), a.numel(), stream_ptr()), "axpby")
+    return out
+
+
+def to_image(x):
+    x = _f32(x)
+    out = torch.empty_like(x)
+    check(_lib.lib().sdmi_to_image(ptr(x), ptr(out), x.numel(), stream_ptr()), "to_image")
+    return out

@@ -1,0 +1,320 @@
+"""GPU: every HIP kernel, called through the C ABI, against (a) plain fp32 torch-CPU references of
+the same op and (b) the golden block vectors the reference produced (tests/golden/g2_blocks.npz).
+
+Tolerances are max|a-b|/max|b|: fp32 mode 2e-5 per op (fp32 MFMA accumulation order differs from the
+CPU's), fp16 3e-3, bf16 2e-2 per op -- well inside the per-UNet-call bars (1e-4 / 2e-2).
+"""
+import importlib
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import golden, max_rel_err, g2_u, structure as S, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32": 2e-5, "fp16": 3e-3, "bf16": 2e-2}
+DTYPES = ["fp32", "fp16", "bf16"]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return importlib.import_module("stable-diffusion_amd.ops")
+
+
+def tdt(name):
+    return {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[name]
+
+
+def nhwc(x, dt):
+    """NCHW fp32 cpu -> NHWC device tensor of dtype dt."""
+    return x.permute(0, 2, 3, 1).contiguous().cuda().to(tdt(dt))
+
+
+def nchw(y):
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def q(x, dt):
+    """Quantise a CPU fp32 tensor to what the device sees in dtype dt (so the reference uses equal inputs)."""
+    return x.to(tdt(dt)).float()
+
+
+def rnd(key, shape, lo=-1., hi=1.):
+    return synth.uniform(3, "ops." + key, shape, lo, hi)
+
+
+CONV_CASES = [
+    # name, B, H, W, C0, C1, Cout, taps, stride, up, splits
+    ("small", 2, 8, 8, 64, 0, 128, 9, 1, 0, 1),
+    ("edge_mn", 2, 6, 6, 64, 0, 320, 9, 1, 0, 1),
+    ("c320", 1, 16, 16, 320, 0, 320, 9, 1, 0, 1),
+    ("down", 2, 16, 16, 128, 0, 128, 9, 2, 0, 1),
+    ("down_odd", 1, 9, 9, 64, 0, 64, 9, 2, 0, 1),
+    ("up", 2, 8, 8, 128, 0, 64, 9, 1, 1, 1),
+    ("concat", 2, 8, 8, 128, 64, 192, 9, 1, 0, 1),
+    ("concat1x1", 2, 8, 8, 128, 64, 192, 1, 1, 0, 1),
+    ("splitk", 2, 8, 8, 256, 0, 128, 9, 1, 0, 4),
+    ("splitk_concat", 1, 8, 8, 128, 128, 64, 9, 1, 0, 3),
+    ("pointwise", 1, 24, 24, 128, 0, 256, 1, 1, 0, 1),
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d(ops, dt, case):
+    name, B, H, W, C0, C1, Cout, taps, stride, up, splits = case
+    k = 3 if taps == 9 else 1
+    x = q(rnd(name + ".x", (B, C0 + C1, H, W)), dt)
+    w = q(rnd(name + ".w", (Cout, C0 + C1, k, k), -0.05, 0.05), dt)
+    b = rnd(name + ".b", (Cout,))
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    ref = F.conv2d(xin, w, b, stride=stride, padding=1 if taps == 9 else 0)
+    wp = ops.pack_weight(w.cuda(), dt)
+    x0 = nhwc(x[:, :C0], dt)
+    x1 = nhwc(x[:, C0:], dt) if C1 else None
+    y = ops.conv2d(x0, wp, b.cuda(), taps=taps, stride=stride, up=bool(up), x1=x1, splits=splits)
+    assert tuple(y.shape) == (B, ref.shape[2], ref.shape[3], Cout)
+    assert max_rel_err(nchw(y), ref) < TOL[dt], name
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv2d_epilogues(ops, dt):
+    """bias + per-sample row add (time embedding) + residual, with and without split-K."""
+    B, H, W, C, Cout = 2, 8, 8, 128, 192
+    x = q(rnd("epi.x", (B, C, H, W)), dt)
+    w = q(rnd("epi.w", (Cout, C, 3, 3), -0.05, 0.05), dt)
+    b = rnd("epi.b", (Cout,))
+    emb = rnd("epi.emb", (B, 256))           # wider row stride than Cout is exercised through a slice
+    res = q(rnd("epi.res", (B, Cout, H, W)), dt)
+    ref = F.conv2d(x, w, b, padding=1) + emb[:, :Cout, None, None] + res
+    wp = ops.pack_weight(w.cuda(), dt)
+    for splits in (1, 3):
+        y = ops.conv2d(nhwc(x, dt), wp, b.cuda(), taps=9, rowadd=emb[:, :Cout].contiguous().cuda(),
+                       resid=nhwc(res, dt), splits=splits)
+        assert max_rel_err(nchw(y), ref) < TOL[dt], splits
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_linear_geglu(ops, dt):
+    rows, d = 200, 128
+    x = q(rnd("geglu.x", (rows, d)), dt)
+    w = q(rnd("geglu.w", (8 * d, d), -0.1, 0.1), dt)
+    b = rnd("geglu.b", (8 * d,))
+    a, g = F.linear(x, w, b).chunk(2, dim=-1)
+    ref = a * F.gelu(g)
+    wp, bp = ops.pack_geglu(w.cuda(), b.cuda(), dt)
+    for splits in (1, 2):
+        y = ops.linear(x.cuda().to(tdt(dt)), wp, bp, geglu=True, splits=splits)
+        assert tuple(y.shape) == (rows, 4 * d)
+        assert max_rel_err(y.float().cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C0,C1,HW", [(320, 0, 16), (128, 0, 24), (1280, 640, 8), (2560, 0, 4), (64, 64, 10)])
+def test_groupnorm(ops, dt, C0, C1, HW):
+    C = C0 + C1
+    x = q(rnd(f"gn{C0}_{C1}.x", (2, C, HW, HW), -3., 5.), dt)
+    g = rnd("gn.g", (C,), 0.5, 1.5)
+    b = rnd("gn.b", (C,))
+    for silu, eps in ((True, 1e-5), (False, 1e-6)):
+        ref = F.group_norm(x, 32, g, b, eps)
+        if silu:
+            ref = F.silu(ref)
+        y = ops.groupnorm(nhwc(x[:, :C0], dt), g.cuda(), b.cuda(), eps, silu=silu,
+                          x1=nhwc(x[:, C0:], dt) if C1 else None)
+        assert max_rel_err(nchw(y), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("d", [320, 640, 1280, 512])
+def test_layernorm(ops, dt, d):
+    x = q(rnd(f"ln{d}.x", (70, d), -3., 5.), dt)
+    g = rnd("ln.g", (d,), 0.5, 1.5)
+    b = rnd("ln.b", (d,))
+    ref = F.layer_norm(x, (d,), g, b, 1e-5)
+    y = ops.layernorm(x.cuda().to(tdt(dt)), g.cuda(), b.cuda())
+    assert max_rel_err(y.float().cpu(), ref) < TOL[dt]
+
+
+def _attn_ref(qv, kv, vv, heads):
+    B, Nq, C = qv.shape
+    d = C // heads
+    sp = lambda t: t.reshape(B, t.shape[1], heads, d).permute(0, 2, 1, 3)
+    s = torch.matmul(sp(qv), sp(kv).transpose(-1, -2)) * d ** -0.5
+    return torch.matmul(s.softmax(-1), sp(vv)).permute(0, 2, 1, 3).reshape(B, Nq, C)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("d,Nq,Nk", [(40, 256, 256), (40, 144, 77), (80, 64, 64), (80, 200, 77), (160, 64, 64),
+                                     (160, 36, 77), (40, 1024, 1024)])
+def test_attention(ops, dt, impl, d, Nq, Nk):
+    heads, B = 8, 2
+    C = heads * d
+    # scores of a few units so that the softmax is far from uniform
+    qv = q(rnd(f"att{d}.q", (B, Nq, C), -2., 2.), dt)
+    kv = q(rnd(f"att{d}.k", (B, Nk, C), -2., 2.), dt)
+    vv = q(rnd(f"att{d}.v", (B, Nk, C), -1., 1.), dt)
+    ref = _attn_ref(qv, kv, vv, heads)
+    dev = lambda t: t.cuda().to(tdt(dt))
+    y = ops.attention(dev(qv), dev(kv), dev(vv), heads, impl=impl)
+    assert max_rel_err(y.float().cpu(), ref) < TOL[dt] * 2
+    if Nq == Nk:
+        # fused q|k|v buffer with row stride 3C, as the UNet executor lays it out
+        qkv = torch.cat([qv, kv, vv], dim=-1).cuda().to(tdt(dt))
+        y2 = ops.attention(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], heads, impl=impl)
+        assert torch.equal(y2, y)
+
+
+def test_attention_forced_rescale(ops):
+    """A key far above the running max late in the sequence forces the online-softmax rescale path."""
+    heads, B, d, N = 8, 1, 40, 256
+    C = heads * d
+    qv = rnd("attspike.q", (B, N, C), -1., 1.)
+    kv = rnd("attspike.k", (B, N, C), -1., 1.)
+    vv = rnd("attspike.v", (B, N, C), -1., 1.)
+    kv[:, 200] = qv[:, 17] * 6.0          # spikes the score of query 17 (and others) at key 200
+    for dt in ("fp32", "fp16"):
+        qq, kk, vq = q(qv, dt), q(kv, dt), q(vv, dt)
+        ref = _attn_ref(qq, kk, vq, heads)
+        dev = lambda t: t.cuda().to(tdt(dt))
+        for impl in (0, 1):
+            y = ops.attention(dev(qq), dev(kk), dev(vq), heads, impl=impl)
+            assert max_rel_err(y.float().cpu(), ref) < TOL[dt] * 2
+
+
+def test_timestep_embedding_g1(ops):
+    g = golden("g1_timestep_embedding")
+    y = ops.timestep_embedding(g["t"].cuda(), 320).cpu()
+    # cos/sin of arguments up to ~1e3: a 1-ulp difference in exp() moves the result by <= 1.2e-4
+    assert float((y - g["emb"]).abs().max()) < 2.5e-4
+    assert max_rel_err(y[:, :8], g["emb"][:, :8]) < 2.5e-4
+
+
+def test_small_linear(ops):
+    x = rnd("sl.x", (5, 320))
+    w = rnd("sl.w", (1280, 320), -0.1, 0.1)
+    b = rnd("sl.b", (1280,))
+    ref = F.silu(F.linear(F.silu(x), w, b))
+    y = ops.small_linear(x.cuda(), w.cuda(), b.cuda(), act_in=1, act_out=1).cpu()
+    assert max_rel_err(y, ref) < 2e-6
+    x = rnd("sl.x2", (18, 64))
+    ref = F.linear(x, w[:, :64].contiguous(), None)
+    y = ops.small_linear(x.cuda(), w[:, :64].contiguous().cuda()).cpu()
+    assert max_rel_err(y, ref) < 2e-6
+
+
+def test_ddim_step_g5_bit_exact(ops):
+    """The fused CFG + DDIM update reproduces the reference's fp32 results bit for bit."""
+    from oracle import sampler_ref
+    g = golden("g5_sampler_kat")
+    tab = sampler_ref.ddpm_tables()
+    x, noise = g["x"].cuda(), g["noise"].cuda()
+    eps = torch.cat([g["e_u"], g["e_c"]]).cuda()
+    for eta in (0.0, 0.5):
+        d = sampler_ref.ddim_tables(tab["alphas_cumprod"], 50, eta)
+        for index in (49, 20, 0):
+            xp, p0 = ops.ddim_step(x, eps, True, 7.5, d["alphas"][index], d["alphas_prev"][index],
+                                   d["sigmas"][index], d["sqrt_one_minus_alphas"][index], noise=noise)
+            assert torch.equal(p0.cpu(), g[f"eta{eta}.i{index}.pred_x0"])
+            assert torch.equal(xp.cpu(), g[f"eta{eta}.i{index}.x_prev"])
+    d = sampler_ref.ddim_tables(tab["alphas_cumprod"], 50, 0.0)
+    for tidx in (36, 49):
+        ca = float(torch.sqrt(torch.tensor(d["alphas"][tidx])))
+        out = ops.axpby(x, noise, ca, float(d["sqrt_one_minus_alphas"][tidx]))
+        assert torch.equal(out.cpu(), g[f"stochastic_encode.t{tidx}"])
+
+
+# ---- golden block vectors (reference classes' own outputs) -------------------------------------------
+def _sd(shapes):
+    return synth.synth_state_dict(shapes, 0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_g2_norms(ops, dt):
+    g = golden("g2_blocks")
+    sd = _sd({"g2.gn32.norm.weight": (320,), "g2.gn32.norm.bias": (320,), "g2.normalize.norm.weight": (640,),
+              "g2.normalize.norm.bias": (640,), "g2.ln.norm.weight": (320,), "g2.ln.norm.bias": (320,)})
+    y = ops.groupnorm(nhwc(g2_u("gn32.x", (2, 320, 8, 8)), dt), sd["g2.gn32.norm.weight"].cuda(),
+                      sd["g2.gn32.norm.bias"].cuda(), 1e-5, silu=True)
+    assert max_rel_err(nchw(y), g["gn32_silu"]) < TOL[dt]
+    y = ops.groupnorm(nhwc(g2_u("normalize.x", (2, 640, 8, 8)), dt), sd["g2.normalize.norm.weight"].cuda(),
+                      sd["g2.normalize.norm.bias"].cuda(), 1e-6)
+    assert max_rel_err(nchw(y), g["normalize"]) < TOL[dt]
+    y = ops.layernorm(g2_u("ln.x", (2, 64, 320)).reshape(128, 320).cuda().to(tdt(dt)), sd["g2.ln.norm.weight"].cuda(),
+                      sd["g2.ln.norm.bias"].cuda())
+    assert max_rel_err(y.float().cpu().reshape(2, 64, 320), g["layernorm"]) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("dh", [40, 80, 160])
+def test_g2_cross_attention_module(ops, dt, dh):
+    """CrossAttention.forward (to_q/to_k/to_v -> softmax(qk^T)v -> to_out) composed from the device ops."""
+    g = golden("g2_blocks")
+    d = 8 * dh
+    ctx = g2_u("ctx", (2, 77, 768))
+    for kind, cdim, context in (("self", d, None), ("cross", 768, ctx)):
+        p = f"g2.{kind}{dh}"
+        sd = _sd({f"{p}.to_q.weight": (d, d), f"{p}.to_k.weight": (d, cdim), f"{p}.to_v.weight": (d, cdim),
+                  f"{p}.to_out.0.weight": (d, d), f"{p}.to_out.0.bias": (d,)})
+        x = g2_u(f"{kind}{dh}.x", (2, 64, d)).reshape(128, d).cuda().to(tdt(dt))
+        c = x if context is None else context.reshape(154, 768).cuda().to(tdt(dt))
+        pw = lambda k: ops.pack_weight(sd[k].cuda(), dt)
+        qv = ops.linear(x, pw(f"{p}.to_q.weight")).view(2, 64, d)
+        kv = ops.linear(c, pw(f"{p}.to_k.weight")).view(2, -1, d)
+        vv = ops.linear(c, pw(f"{p}.to_v.weight")).view(2, -1, d)
+        o = ops.attention(qv, kv, vv, 8).view(128, d)
+        y = ops.linear(o, pw(f"{p}.to_out.0.weight"), sd[f"{p}.to_out.0.bias"].cuda())
+        assert max_rel_err(y.float().cpu().view(2, 64, d), g[f"{kind}{dh}"]) < TOL[dt] * 2, p
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_g2_feedforward_down_up(ops, dt):
+    g = golden("g2_blocks")
+    p = "g2.ff"
+    sd = _sd({f"{p}.net.0.proj.weight": (2560, 320), f"{p}.net.0.proj.bias": (2560,),
+              f"{p}.net.2.weight": (320, 1280), f"{p}.net.2.bias": (320,)})
+    x = g2_u("ff.x", (2, 64, 320)).reshape(128, 320).cuda().to(tdt(dt))
+    wp, bp = ops.pack_geglu(sd[f"{p}.net.0.proj.weight"].cuda(), sd[f"{p}.net.0.proj.bias"].cuda(), dt)
+    h = ops.linear(x, wp, bp, geglu=True)
+    y = ops.linear(h, ops.pack_weight(sd[f"{p}.net.2.weight"].cuda(), dt), sd[f"{p}.net.2.bias"].cuda())
+    assert max_rel_err(y.float().cpu().view(2, 64, 320), g["ff"]) < TOL[dt] * 2
+    sd = _sd({"g2.down.op.weight": (320, 320, 3, 3), "g2.down.op.bias": (320,),
+              "g2.up.conv.weight": (320, 320, 3, 3), "g2.up.conv.bias": (320,)})
+    y = ops.conv2d(nhwc(g2_u("down.x", (2, 320, 8, 8)), dt), ops.pack_weight(sd["g2.down.op.weight"].cuda(), dt),
+                   sd["g2.down.op.bias"].cuda(), stride=2)
+    assert max_rel_err(nchw(y), g["down"]) < TOL[dt]
+    y = ops.conv2d(nhwc(g2_u("up.x", (2, 320, 8, 8)), dt), ops.pack_weight(sd["g2.up.conv.weight"].cuda(), dt),
+                   sd["g2.up.conv.bias"].cuda(), up=True)
+    assert max_rel_err(nchw(y), g["up"]) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("name,cin", [("res_a", 320), ("res_b", 640)])
+def test_g2_resblock(ops, dt, name, cin):
+    """ResBlock._forward composed from the device ops in the executor's order."""
+    from collections import OrderedDict
+    g = golden("g2_blocks")
+    spec = S.ResSpec("g2." + name, cin, 320)
+    shapes = OrderedDict()
+    S._res_params(spec, 1280, shapes)
+    sd = {k: v.cuda() for k, v in _sd(shapes).items()}
+    p = spec.prefix
+    x = nhwc(g2_u(name + ".x", (2, cin, 8, 8)), dt)
+    emb = g2_u("emb", (2, 1280)).cuda()
+    e = ops.small_linear(emb, sd[p + ".emb_layers.1.weight"], sd[p + ".emb_layers.1.bias"], act_in=1)
+    h = ops.groupnorm(x, sd[p + ".in_layers.0.weight"], sd[p + ".in_layers.0.bias"], 1e-5, silu=True)
+    h = ops.conv2d(h, ops.pack_weight(sd[p + ".in_layers.2.weight"], dt), sd[p + ".in_layers.2.bias"], rowadd=e)
+    h = ops.groupnorm(h, sd[p + ".out_layers.0.weight"], sd[p + ".out_layers.0.bias"], 1e-5, silu=True)
+    if cin != 320:
+        skip = ops.conv2d(x, ops.pack_weight(sd[p + ".skip_connection.weight"], dt),
+                          sd[p + ".skip_connection.bias"], taps=1)
+    else:
+        skip = x
+    y = ops.conv2d(h, ops.pack_weight(sd[p + ".out_layers.3.weight"], dt), sd[p + ".out_layers.3.bias"], resid=skip)
+    assert max_rel_err(nchw(y), g[name]) < TOL[dt] * 2

@@ -43,14 +43,16 @@ struct GnParams {
   float* stats;     // [B][G][2]  (mean, rstd)
 };
 
+constexpr int GN_LDS_SLOTS = 1024;   // >= max(blockDim, C / elements-per-vector)
+
 template <typename T>
 __global__ void gn_partial_kernel(GnParams p) {
   constexpr int EPV = VecOf<T>::N;
-  __shared__ float s_sum[64], s_sq[64];
+  // per-(pixel lane, vector) partial sums: [0]=sum,[1]=sumsq of the vector's first group, [2],[3] of
+  // its second group (a 16-byte vector spans at most two groups)
+  __shared__ float ls[4][GN_LDS_SLOTS];
   const int nvec = p.C / EPV;
   const int chunk = blockIdx.x, b = blockIdx.y;
-  if (threadIdx.x < 64) { s_sum[threadIdx.x] = 0.f; s_sq[threadIdx.x] = 0.f; }
-  __syncthreads();
   // blockDim is nvec * lanes_pix when the vectors of one pixel fit a block (every thread owns one
   // vector and every lanes_pix-th pixel); otherwise a thread strides over vectors and takes all pixels.
   const bool fits = (int)blockDim.x >= nvec;
@@ -73,22 +75,31 @@ __global__ void gn_partial_kernel(GnParams p) {
 #pragma unroll
       for (int e = 0; e < EPV; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
     }
-    // fold the vector's channels into (at most two) groups, then into LDS
-    const int g0 = c / p.cpg;
-    const int boundary = (g0 + 1) * p.cpg;
+    const int boundary = (c / p.cpg + 1) * p.cpg;
     float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
       if (c + e < boundary) { sa += s[e]; qa += q[e]; } else { sb += s[e]; qb += q[e]; }
     }
-    atomicAdd(&s_sum[g0], sa); atomicAdd(&s_sq[g0], qa);
-    if (boundary < c + EPV) { atomicAdd(&s_sum[g0 + 1], sb); atomicAdd(&s_sq[g0 + 1], qb); }
+    const int slot = pix_lane * nvec + v;
+    ls[0][slot] = sa; ls[1][slot] = qa; ls[2][slot] = sb; ls[3][slot] = qb;
   }
   __syncthreads();
-  if (threadIdx.x < p.groups) {
-    float* dst = p.partial + (((size_t)b * p.chunks + chunk) * p.groups + threadIdx.x) * 2;
-    dst[0] = s_sum[threadIdx.x];
-    dst[1] = s_sq[threadIdx.x];
+  // fixed-order fold per group: results do not depend on thread timing
+  if ((int)threadIdx.x < p.groups) {
+    const int g = threadIdx.x;
+    const int v_lo = (g * p.cpg) / EPV, v_hi = ((g + 1) * p.cpg - 1) / EPV;
+    float s = 0.f, q = 0.f;
+    for (int pl = 0; pl < lanes_pix; ++pl)
+      for (int v = v_lo; v <= v_hi; ++v) {
+        const int slot = pl * nvec + v;
+        const int g0 = (v * EPV) / p.cpg;
+        if (g0 == g) { s += ls[0][slot]; q += ls[1][slot]; }
+        else { s += ls[2][slot]; q += ls[3][slot]; }
+      }
+    float* dst = p.partial + (((size_t)b * p.chunks + chunk) * p.groups + g) * 2;
+    dst[0] = s;
+    dst[1] = q;
   }
 }
 
@@ -164,6 +175,7 @@ int launch_gn(const GroupNormArgs& a, hipStream_t stream) {
   p.partial = a.scratch;
   p.stats = a.scratch + (size_t)p.B * GN_MAX_CHUNKS * p.groups * 2;
   const int nvec = p.C / EPV;
+  SDMI_REQUIRE(nvec <= GN_LDS_SLOTS, "groupnorm: C=%d too wide", p.C);
   int threads = nvec <= 256 ? nvec * (256 / nvec) : 256;
   hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(p.chunks, p.B), dim3(threads), 0, stream, p);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((p.B * p.groups + 63) / 64), dim3(64), 0, stream, p);

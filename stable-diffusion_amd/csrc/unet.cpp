@@ -101,9 +101,11 @@ struct sdmi_unet {
   };
   GraphKey gkey; bool ghave = false;
   hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
+  hipStream_t cap_stream = nullptr;      // capture happens here; replay goes to the caller's stream
 
   ~sdmi_unet() {
     drop_graph();
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
     mem.release_all();
   }
   void drop_graph() {
@@ -600,13 +602,18 @@ struct sdmi_unet {
     memset(&k, 0, sizeof(k));
     k.x = f.x; k.c0 = f.n_concat > 0 ? f.concat[0] : nullptr; k.c1 = f.n_concat > 1 ? f.concat[1] : nullptr;
     k.t = f.t; k.out = f.out; k.n_concat = f.n_concat; k.cc0 = f.cc[0]; k.cc1 = f.cc[1];
-    k.B = f.B; k.H = f.H; k.W = f.W; k.stream = f.s;
+    k.B = f.B; k.H = f.H; k.W = f.W; k.stream = nullptr;
     if (!(ghave && k == gkey)) {
       drop_graph();
-      SDMI_CHECK_HIP(hipStreamBeginCapture(f.s, hipStreamCaptureModeThreadLocal));
-      const int rc = run(f);
+      // the caller's stream may be the legacy default stream, which cannot be captured: record the
+      // launch sequence on a private stream (nothing executes there) and replay it on f.s
+      if (!cap_stream) SDMI_CHECK_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+      Fwd fc = f;
+      fc.s = cap_stream;
+      SDMI_CHECK_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+      const int rc = run(fc);
       hipGraph_t g = nullptr;
-      const hipError_t e = hipStreamEndCapture(f.s, &g);
+      const hipError_t e = hipStreamEndCapture(cap_stream, &g);
       if (rc != SDMI_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
       if (e != hipSuccess) { sdmi_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return SDMI_EHIP; }
       graph = g;

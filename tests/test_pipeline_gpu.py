@@ -1,0 +1,143 @@
+"""GPU: the caller-visible pipeline (DDIMSampler.sample / decode / stochastic_encode, decode_first_stage,
+image post-scale) through the C ABI against the reference's golden trajectories.
+
+Bars: fp32 mode latent max-rel-err <= 1e-4 per UNet call (the loops below chain 5-10 calls, bar 5e-4);
+fp16 mode final decoded image PSNR >= 35 dB after 50 DDIM steps (G7).
+"""
+import importlib
+
+import pytest
+import torch
+
+from _util import golden, max_rel_err, psnr, device_latent_diffusion, drop_models
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _cleanup():
+    yield
+    drop_models()
+
+
+def sampler_for(model):
+    return importlib.import_module("stable-diffusion_amd").DDIMSampler(model)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "fp16"])
+def test_g8_vae_decode(dt):
+    model = device_latent_diffusion(4, "crossattn", dt)
+    g = golden("g8_vae")
+    raw = model.first_stage_model.decode(g["z"].cuda())
+    dec = model.decode_first_stage(g["z"].cuda())
+    torch.cuda.synchronize()
+    assert tuple(dec.shape) == (1, 3, 256, 256)
+    e1, e2 = max_rel_err(raw.cpu(), g["dec_raw"]), max_rel_err(dec.cpu(), g["dec"])
+    print(f"vae {dt}: raw {e1:.3e} scaled {e2:.3e}")
+    bar = 1e-4 if dt == "fp32" else 2e-2
+    assert e1 < bar and e2 < bar
+
+
+@pytest.mark.parametrize("dt", ["fp32", "fp16"])
+def test_g6_c1_txt2img_end_to_end(dt):
+    """C1: 256x256, 10 DDIM steps, batch 1, CFG 7.5, eta 0, + VAE decode + clamp."""
+    model = device_latent_diffusion(4, "crossattn", dt)
+    ops = importlib.import_module("stable-diffusion_amd.ops")
+    g = golden("g6_c1_e2e")
+    sampler = sampler_for(model)
+    cond = torch.cat([g["uc"].float(), g["c"].float()]).cuda()
+    z, inter = sampler.sample(S=10, batch_size=1, shape=[4, 32, 32], conditioning=cond,
+                              unconditional_guidance_scale=7.5, unconditional_conditioning=True, eta=0.,
+                              x_T=g["x_T"].cuda(), verbose=False)
+    img = ops.to_image(model.decode_first_stage(z))
+    torch.cuda.synchronize()
+    assert set(inter.keys()) == {"x_inter", "pred_x0"}
+    err = max_rel_err(z.cpu(), g["z"])
+    p = psnr(img.cpu(), g["image"].float())
+    print(f"g6 {dt}: latent err {err:.3e}, image PSNR {p:.1f} dB")
+    if dt == "fp32":
+        assert err < 5e-4
+        assert p > 60.0
+    else:
+        assert err < 5e-2
+        assert p > 35.0
+
+
+def test_g7_c3_50_step_trajectory_psnr_fp16():
+    """512x512, 50 DDIM steps, CFG 7.5: fp16 path vs the reference fp32 image, PSNR >= 35 dB."""
+    model = device_latent_diffusion(4, "crossattn", "fp16")
+    ops = importlib.import_module("stable-diffusion_amd.ops")
+    g = golden("g7_c3_traj")
+    sampler = sampler_for(model)
+    cond = torch.cat([g["uc"].float(), g["c"].float()]).cuda()
+    seen = {}
+    z, _ = sampler.sample(S=50, batch_size=1, shape=[4, 64, 64], conditioning=cond,
+                          unconditional_guidance_scale=7.5, unconditional_conditioning=True, eta=0.,
+                          x_T=g["x_T"].cuda(), verbose=False,
+                          img_callback=lambda p0, i: seen.__setitem__(i, p0.clone()) if i in (0, 9, 24, 49) else None)
+    img = ops.to_image(model.decode_first_stage(z))
+    torch.cuda.synchronize()
+    for i in (0, 9, 24, 49):
+        e = max_rel_err(seen[i].cpu(), g[f"pred_x0_step{i}"])
+        print(f"g7 pred_x0 step {i}: {e:.3e}")
+        assert e < 5e-2
+    err = max_rel_err(z.cpu(), g["z"])
+    p = psnr(img.cpu(), g["image"].float())
+    print(f"g7 fp16: final latent err {err:.3e}, image PSNR {p:.1f} dB")
+    assert p >= 35.0
+
+
+@pytest.mark.parametrize("dt", ["fp32", "fp16"])
+def test_g9_img2img(dt):
+    """stochastic_encode at strength 0.75 (t_enc = 37 of 50) then decode() with CFG 5.0."""
+    model = device_latent_diffusion(4, "crossattn", dt)
+    g = golden("g9_img2img")
+    sampler = sampler_for(model)
+    sampler.make_schedule(50, ddim_eta=0.0, verbose=False)
+    z_enc = sampler.stochastic_encode(g["init"].cuda(), torch.tensor([37]), noise=g["noise"].cuda())
+    assert torch.equal(z_enc.cpu(), g["z_enc"])            # elementwise fp32: bit exact
+    cond = torch.cat([g["uc"].float(), g["c"].float()]).cuda()
+    z = sampler.decode(z_enc, cond, 37, unconditional_guidance_scale=5.0, unconditional_conditioning=True,
+                       verbose=False)
+    torch.cuda.synchronize()
+    err = max_rel_err(z.cpu(), g["z"])
+    print(f"g9 img2img {dt}: {err:.3e}")
+    assert err < (2e-3 if dt == "fp32" else 5e-2)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "fp16"])
+def test_g9_inpaint_hybrid(dt):
+    """Text-guided inpainting: hybrid conditioning dict, 9-channel UNet, 5 steps."""
+    model = device_latent_diffusion(9, "hybrid", dt)
+    g = golden("g9_inpaint")
+    sampler = sampler_for(model)
+    cond = {"c_concat": [[g["mask"].cuda()], [g["masked"].cuda()]],
+            "c_crossattn": [torch.cat([g["uc"].float(), g["c"].float()]).cuda()]}
+    z, _ = sampler.sample(S=5, batch_size=1, shape=[4, 32, 32], conditioning=cond,
+                          unconditional_guidance_scale=7.5, unconditional_conditioning=True, eta=0.,
+                          x_T=g["x_T"].cuda(), verbose=False)
+    torch.cuda.synchronize()
+    err = max_rel_err(z.cpu(), g["z"])
+    print(f"g9 inpaint {dt}: {err:.3e}")
+    assert err < (5e-4 if dt == "fp32" else 5e-2)
+
+
+def test_eta_noise_path_and_p_sample_ddim_signature():
+    """eta > 0 draws noise every step; with explicit noise the single-step API matches the oracle."""
+    from oracle import sampler_ref
+    model = device_latent_diffusion(4, "crossattn", "fp32")
+    sampler = sampler_for(model)
+    sampler.make_schedule(50, ddim_eta=0.5, verbose=False)
+    g3 = golden("g3_unet_c1")
+    x = g3["x"].cuda()
+    ctx = g3["ctx"].float().cuda()
+    noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(5)).cuda()
+    index = 45
+    t = torch.full((1,), int(sampler.ddim_timesteps[index]), dtype=torch.long)
+    x_prev, pred_x0 = sampler.p_sample_ddim(x, ctx, t, index, unconditional_guidance_scale=1.0, noise=noise)
+    eps = model.apply_model(x, t.cuda(), ctx)
+    tab = sampler_ref.ddim_tables(sampler_ref.ddpm_tables()["alphas_cumprod"], 50, 0.5)
+    xp_ref, p0_ref = sampler_ref.ddim_update(x.cpu(), eps.cpu(), tab["alphas"][index], tab["alphas_prev"][index],
+                                             tab["sigmas"][index], tab["sqrt_one_minus_alphas"][index], noise.cpu())
+    assert torch.equal(pred_x0.cpu(), p0_ref)
+    assert torch.equal(x_prev.cpu(), xp_ref)

@@ -1,0 +1,80 @@
+"""GPU: the whole UNet denoiser through the C ABI against the reference's golden outputs (G3).
+
+Bars (BASELINE north_star): per-UNet-call max|a-b|/max|b| <= 1e-4 in fp32 mode, <= 2e-2 in fp16/bf16.
+"""
+import pytest
+import torch
+
+from _util import golden, max_rel_err, device_unet, drop_models
+
+pytestmark = pytest.mark.gpu
+
+BAR = {"fp32": 1e-4, "fp16": 2e-2, "bf16": 2e-2}
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _cleanup():
+    yield
+    drop_models()
+
+
+@pytest.mark.parametrize("dt", ["fp32", "fp16", "bf16"])
+def test_g3_unet_c2_and_c1(dt):
+    net = device_unet(4, dt)
+    for name in ("g3_unet_c2", "g3_unet_c1"):
+        g = golden(name)
+        out = net(g["x"].cuda(), g["t"].cuda(), context=g["ctx"].float().cuda())
+        torch.cuda.synchronize()
+        err = max_rel_err(out.cpu(), g["out"])
+        print(f"{name} {dt}: max_rel_err {err:.3e}")
+        assert tuple(out.shape) == tuple(g["out"].shape)
+        assert err < BAR[dt], (name, dt, err)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "fp16"])
+def test_g3_unet_c5_hybrid_9ch_96(dt):
+    """Inpainting UNet: 9 input channels (4 noisy + 1 mask + 4 masked latent), 9216-token attention."""
+    net = device_unet(9, dt)
+    g = golden("g3_unet_c5")
+    out = net(g["x"].cuda(), g["t"].cuda(), context=g["ctx"].float().cuda(),
+              _concat=[g["mask"].cuda(), g["masked"].cuda()])
+    torch.cuda.synchronize()
+    err = max_rel_err(out.cpu(), g["out"])
+    print(f"g3_unet_c5 {dt}: max_rel_err {err:.3e}")
+    assert err < BAR[dt], err
+
+
+def test_graph_replay_equals_eager_and_context_switch():
+    net = device_unet(4, "fp16")
+    g = golden("g3_unet_c2")
+    x, t = g["x"].cuda(), g["t"].cuda()
+    ctx = g["ctx"].float().cuda()
+    out = torch.empty((2, 4, 64, 64), device="cuda")
+    net.set_graph_mode(False)
+    eager = net(x, t, context=ctx, out=out).clone()
+    net.set_graph_mode(True)
+    first = net(x, t, context=ctx, out=out).clone()       # captures
+    second = net(x, t, context=ctx, out=out).clone()      # replays
+    assert torch.equal(eager, first) and torch.equal(first, second)
+    # a new timestep value is read from device memory by the replayed graph
+    t.fill_(1)
+    moved = net(x, t, context=ctx, out=out).clone()
+    assert not torch.equal(moved, second)
+    t.fill_(981)
+    # a different context tensor re-projects K/V; the original one restores the original output
+    other = torch.flip(ctx, dims=[0]).contiguous()
+    swapped = net(x, t, context=other, out=out).clone()
+    assert not torch.equal(swapped, second)
+    back = net(x, t, context=ctx, out=out).clone()
+    assert torch.equal(back, second)
+
+
+def test_errors_are_loud():
+    net = device_unet(4, "fp16")
+    g = golden("g3_unet_c1")
+    with pytest.raises(RuntimeError, match="context was set for batch"):
+        net(g["x"].cuda().repeat(2, 1, 1, 1), g["t"].cuda().repeat(2), context=g["ctx"].float().cuda())
+    with pytest.raises(RuntimeError, match="divisible"):
+        net(torch.zeros(1, 4, 20, 20).cuda(), g["t"].cuda(), context=g["ctx"].float().cuda())
+    with pytest.raises(AssertionError, match="class-conditional"):
+        net(g["x"].cuda(), g["t"].cuda(), context=g["ctx"].float().cuda(), y=torch.zeros(1))

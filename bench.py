@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec for 512x512, 50-step DDIM, classifier-free guidance, on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: batch-8 txt2img (UNet batch 16 with CFG) = 50 x
+[UNet forward + fused CFG/DDIM update] + VAE decode + clamp, fp16 compute, synthetic SD-v1-shaped
+weights, context tensors standing in for the CLIP output, inputs resident in HBM.  With N > 1 every
+rank runs its own batch (weak scaling; samples are independent trajectories) and the decoded images
+are all-gathered over RCCL inside the timed region.  Rank 0 prints one JSON line.
+
+Extra objects on that line:
+  roofline      dominant kernel (implicit-GEMM conv/linear on MFMA): algorithmic FLOPs of its launches /
+                their HIP-event time, measured in this process on one extra eager pass of the same step
+                (events cannot bracket kernels inside a graph replay), against the 2.5 PFLOP/s dense
+                fp16 MFMA peak.
+  cpu_baseline  the CPU oracle (fp32 torch restatement of the reference) timed on this host's cores on a
+                bounded sample (UNet batch-2 forwards + one VAE decode, extrapolated to 50 steps).
+  unet_it_per_s_batch2  the second half of the headline metric: single UNet forward, latent 64x64,
+                batch 2, graph replay.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3}
+UNET_GFLOP_PER_SAMPLE = 803.3        # one sample-forward at latent 64x64 (algorithmic, 2*MACs)
+VAE_GFLOP_PER_IMAGE = 2514.5
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
+    ap.add_argument("--scale", type=float, default=7.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    return ap.parse_args()
+
+
+def prof_read(lib, name):
+    import ctypes
+    ms, n, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+    rc = lib.sdmi_prof_get(name.encode(), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
+    assert rc == 0, lib.sdmi_last_error()
+    return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+
+
+def cpu_baseline(ddim_steps, size):
+    """Oracle on host cores: 2 UNet batch-2 forwards + 1 VAE decode, extrapolated to a full image."""
+    from oracle import unet_ref, vae_ref
+    S = importlib.import_module("stable-diffusion_amd.structure")
+    synth = importlib.import_module("stable-diffusion_amd.synth")
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    h = size // 8
+    st = S.unet_structure(**S.sd_v1_unet_config(4))
+    sd = synth.synth_state_dict(S.unet_param_shapes(st), 0)
+    x = synth.normal(42, "x_T", (2, 4, h, h))
+    ctx = synth.normal(1, "cond_ctx", (2, 77, 768))
+    t = torch.full((2,), 981, dtype=torch.long)
+    unet_ref.unet_forward(sd, st, x[:, :, :16, :16], t, ctx)          # warm the thread pool
+    n_unet = 2
+    t0 = time.perf_counter()
+    for _ in range(n_unet):
+        unet_ref.unet_forward(sd, st, x, t, ctx)
+    t_unet = (time.perf_counter() - t0) / n_unet
+    del sd
+    vst = S.vae_decoder_structure(S.sd_v1_ddconfig(), 4)
+    vsd = synth.synth_state_dict(S.vae_decoder_param_shapes(vst), 0)
+    t0 = time.perf_counter()
+    vae_ref.decode_first_stage(vsd, vst, x[:1])
+    t_vae = time.perf_counter() - t0
+    per_image = ddim_steps * t_unet + t_vae
+    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n_unet} UNet batch-2 forwards ({t_unet:.2f} s each) + 1 VAE decode ({t_vae:.2f} s) at "
+                      f"{size}x{size}, fp32 torch-CPU oracle, extrapolated to {ddim_steps} steps per image",
+            "unet_it_per_s_batch2": 1.0 / t_unet}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    pipeline = importlib.import_module("stable-diffusion_amd.pipeline")
+    sdmi = importlib.import_module("stable-diffusion_amd")
+    _lib = importlib.import_module("stable-diffusion_amd._lib")
+    lib = _lib.lib()
+
+    model = pipeline.build_synthetic_model(4, "crossattn", args.dtype, device=dev)
+    unet = model.model.diffusion_model
+    if args.no_graph:
+        unet.set_graph_mode(False)
+    sampler = sdmi.DDIMSampler(model)
+    B, h = args.batch, args.size // 8
+    first = rank * B                                   # this rank's block of the global sample list
+    uc, c = pipeline.synthetic_conditioning(B, dev, first_sample=first)
+    x_T = pipeline.initial_latents(B, h, h, dev, first_sample=first)
+
+    def step():
+        img, _ = pipeline.txt2img(model, x_T, uc, c, steps=args.ddim_steps, scale=args.scale, sampler=sampler)
+        return pipeline.gather_images(img)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert out.shape[0] == world * B and bool(torch.isfinite(out).all())
+    images = world * B * args.steps
+    value = images / elapsed
+
+    result = {
+        "metric": "images/sec (node) 512x512 50-step DDIM CFG; UNet it/s at batch 2",
+        "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"txt2img {args.size}x{args.size}, {args.ddim_steps} DDIM steps, CFG {args.scale}, "
+                               f"batch {B}/GPU (UNet batch {2 * B}), UNet loop + fused CFG/DDIM update + VAE decode "
+                               f"+ clamp; SD-v1-shaped random weights; context tensors in place of CLIP",
+                   "global_batch": world * B, "latent": [4, h, h], "parallelism": f"replicas x{world} (sample shard)",
+                   "graph_replay": not args.no_graph},
+    }
+
+    if rank == 0:
+        # ---- C2: single UNet forward, batch 2 -------------------------------------------------------
+        x2 = pipeline.initial_latents(1, h, h, dev).repeat(2, 1, 1, 1).contiguous()
+        uc2, c2 = pipeline.synthetic_conditioning(1, dev)
+        ctx2 = torch.cat([uc2, c2])
+        t2 = torch.full((2,), 981, dtype=torch.int64, device=dev)
+        o2 = torch.empty_like(x2)
+        for _ in range(3):
+            unet(x2, t2, context=ctx2, out=o2)
+        torch.cuda.synchronize()
+        n2 = 30
+        t0 = time.perf_counter()
+        for _ in range(n2):
+            unet(x2, t2, context=ctx2, out=o2)
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / n2
+        result["unet_it_per_s_batch2"] = 1.0 / dt2
+        result["unet_batch2_ms"] = 1e3 * dt2
+        result["unet_batch2_tflops"] = 2 * UNET_GFLOP_PER_SAMPLE / dt2 / 1e3
+        # whole-step algorithmic rate
+        step_tflop = (B * (2 * UNET_GFLOP_PER_SAMPLE * args.ddim_steps + VAE_GFLOP_PER_IMAGE)) / 1e3
+        if args.size == 512:
+            result["step_tflops"] = step_tflop / (elapsed / args.steps)
+
+    if rank == 0 and not args.no_roofline:
+        # ---- roofline of the dominant kernel: one extra eager pass of the same step under HIP events ----
+        unet.set_graph_mode(False)
+        lib.sdmi_prof_reset()
+        lib.sdmi_prof_enable(1)
+        step()
+        torch.cuda.synchronize()
+        lib.sdmi_prof_enable(0)
+        gemm = prof_read(lib, "conv_gemm")
+        others = {k: prof_read(lib, k) for k in ("attention", "groupnorm", "layernorm")}
+        lib.sdmi_prof_reset()
+        unet.set_graph_mode(not args.no_graph)
+        achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        result["roofline"] = {
+            "bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv3x3/conv1x1/linear)",
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+            "launches": gemm["launches"], "avg_launch_us": 1e3 * gemm["ms"] / max(1, gemm["launches"]),
+            "flops_per_launch": gemm["flops"] / max(1, gemm["launches"]), "kernel_ms_per_step": gemm["ms"],
+        }
+        tot = gemm["ms"] + sum(v["ms"] for v in others.values())
+        result["kernel_time_share"] = {"conv_gemm": gemm["ms"] / tot,
+                                       **{k: v["ms"] / tot for k, v in others.items()}}
+        att = others["attention"]
+        result["attention_tflops"] = att["flops"] / (att["ms"] * 1e-3) / 1e12 if att["ms"] > 0 else None
+        for k in ("groupnorm", "layernorm"):
+            v = others[k]
+            result[k + "_GBps"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else None
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.ddim_steps, args.size)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

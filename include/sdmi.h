@@ -170,6 +170,16 @@ int sdmi_small_linear(const float* x, const float* w, const float* bias, float* 
 int sdmi_convert_from_f32(const float* x, void* out, int64_t n, int dtype, void* stream);
 int sdmi_convert_to_f32(const void* x, float* out, int64_t n, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement hooks (no counterpart in the reference, which has no profiling): when enabled, every
+ * eager launch of a kernel class is bracketed by HIP events on its stream and the algorithmic
+ * FLOPs / bytes of the launch are tallied.  Classes: "conv_gemm", "attention", "groupnorm",
+ * "layernorm".  Disable HIP-graph replay (sdmi_unet_set_graph_mode(u, 0)) while profiling.
+ * ------------------------------------------------------------------------------------------ */
+int sdmi_prof_enable(int on);
+int sdmi_prof_reset(void);
+int sdmi_prof_get(const char* kernel_class, double* ms_total, int64_t* launches, double* flops, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,9 @@ SIGNATURES = {
                                   c_void_p]),
     "sdmi_convert_from_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "sdmi_convert_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "sdmi_prof_enable": (c_int, [c_int]),
+    "sdmi_prof_reset": (c_int, []),
+    "sdmi_prof_get": (c_int, [c_char_p, P(ctypes.c_double), P(c_int64), P(ctypes.c_double), P(ctypes.c_double)]),
 }
 
 _lib = None

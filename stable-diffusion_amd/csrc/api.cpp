@@ -14,7 +14,72 @@ void sdmi_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- profiler -----------------------------------------------------------------------------------
+#include <string.h>
+#include <vector>
+namespace {
+struct ProfEntry { hipEvent_t a, b; int cls; };
+bool g_prof_on = false;
+std::vector<ProfEntry> g_prof_entries;
+std::vector<hipEvent_t> g_prof_pool;
+double g_prof_flops[PROF_NCLS], g_prof_bytes[PROF_NCLS];
+int64_t g_prof_launches[PROF_NCLS];
+const char* const kProfNames[PROF_NCLS] = {"conv_gemm", "attention", "groupnorm", "layernorm", "other"};
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+
+void prof_begin(int cls, hipStream_t stream, double flops, double bytes) {
+  if (!g_prof_on) return;
+  ProfEntry e{prof_event(), prof_event(), cls};
+  (void)hipEventRecord(e.a, stream);
+  g_prof_entries.push_back(e);
+  g_prof_flops[cls] += flops; g_prof_bytes[cls] += bytes; g_prof_launches[cls] += 1;
+}
+void prof_end(int cls, hipStream_t stream) {
+  if (!g_prof_on) return;
+  for (size_t i = g_prof_entries.size(); i-- > 0;)
+    if (g_prof_entries[i].cls == cls) { (void)hipEventRecord(g_prof_entries[i].b, stream); return; }
+}
+
 extern "C" {
+
+int sdmi_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return SDMI_OK;
+}
+int sdmi_prof_reset(void) {
+  for (auto& e : g_prof_entries) { g_prof_pool.push_back(e.a); g_prof_pool.push_back(e.b); }
+  g_prof_entries.clear();
+  memset(g_prof_flops, 0, sizeof(g_prof_flops));
+  memset(g_prof_bytes, 0, sizeof(g_prof_bytes));
+  memset(g_prof_launches, 0, sizeof(g_prof_launches));
+  return SDMI_OK;
+}
+int sdmi_prof_get(const char* kernel_class, double* ms_total, int64_t* launches, double* flops, double* bytes) {
+  SDMI_REQUIRE(kernel_class, "prof_get: null class");
+  int cls = -1;
+  for (int i = 0; i < PROF_NCLS; ++i)
+    if (strcmp(kernel_class, kProfNames[i]) == 0) cls = i;
+  SDMI_REQUIRE(cls >= 0, "prof_get: unknown class '%s'", kernel_class);
+  SDMI_CHECK_HIP(hipDeviceSynchronize());
+  double ms = 0.0;
+  for (const auto& e : g_prof_entries)
+    if (e.cls == cls) {
+      float t = 0.f;
+      SDMI_CHECK_HIP(hipEventElapsedTime(&t, e.a, e.b));
+      ms += t;
+    }
+  if (ms_total) *ms_total = ms;
+  if (launches) *launches = g_prof_launches[cls];
+  if (flops) *flops = g_prof_flops[cls];
+  if (bytes) *bytes = g_prof_bytes[cls];
+  return SDMI_OK;
+}
 
 int sdmi_version(void) { return SDMI_VERSION; }
 const char* sdmi_last_error(void) { return g_err; }

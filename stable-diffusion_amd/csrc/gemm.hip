@@ -374,6 +374,8 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
 
   SDMI_TRY(conv_gemm_init());
+  ProfScope prof(PROF_CONV_GEMM, stream, 2.0 * p.M * (double)p.N * p.K,
+                 ((double)p.M * p.K / (p.taps == 9 ? 9 : 1) + (double)p.N * p.K + (double)p.M * p.N) * sizeof(T));
   dim3 grid(p.tiles_m * p.tiles_n, splits);
   hipLaunchKernelGGL(conv_gemm_kernel<T>, grid, dim3(NTHREADS), LDS_BYTES, stream, p);
   SDMI_CHECK_HIP(hipGetLastError());

@@ -177,6 +177,7 @@ int launch_gn(const GroupNormArgs& a, hipStream_t stream) {
   const int nvec = p.C / EPV;
   SDMI_REQUIRE(nvec <= GN_LDS_SLOTS, "groupnorm: C=%d too wide", p.C);
   int threads = nvec <= 256 ? nvec * (256 / nvec) : 256;
+  ProfScope prof(PROF_GROUPNORM, stream, 0.0, 2.0 * p.B * (double)p.HW * p.C * sizeof(T));
   hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(p.chunks, p.B), dim3(threads), 0, stream, p);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((p.B * p.groups + 63) / 64), dim3(64), 0, stream, p);
   const size_t total = (size_t)p.B * p.HW * nvec;
@@ -241,6 +242,7 @@ int launch_ln(const void* x, void* out, const float* gamma, const float* beta, i
   SDMI_REQUIRE(d % EPV == 0 && d > 0 && rows > 0, "layernorm: d=%d must be a positive multiple of %d", d, EPV);
   const int nvec = d / EPV;
   const dim3 grid((rows + 3) / 4), block(256);
+  ProfScope prof(PROF_LAYERNORM, stream, 0.0, 2.0 * rows * (double)d * sizeof(T));
   if (nvec <= 64 * 3)
     hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, stream, (const T*)x, (T*)out, gamma, beta, rows, d, eps);
   else if (nvec <= 64 * 8)

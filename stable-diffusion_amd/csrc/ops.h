@@ -3,6 +3,16 @@
 #pragma once
 #include "common.h"
 
+// ---- optional per-kernel-class timing with HIP events (eager launches only; off by default) -------
+enum { PROF_CONV_GEMM = 0, PROF_ATTENTION = 1, PROF_GROUPNORM = 2, PROF_LAYERNORM = 3, PROF_OTHER = 4, PROF_NCLS = 5 };
+void prof_begin(int cls, hipStream_t stream, double flops, double bytes);
+void prof_end(int cls, hipStream_t stream);
+struct ProfScope {
+  int cls; hipStream_t s;
+  ProfScope(int c, hipStream_t st, double flops, double bytes) : cls(c), s(st) { prof_begin(c, st, flops, bytes); }
+  ~ProfScope() { prof_end(cls, s); }
+};
+
 // ---- implicit-GEMM convolution / linear ---------------------------------------------------------
 // out[m][n] = epilogue( sum_k A(m,k) * Wp[n][k] ),  m = output pixel (b, oy, ox), n = out channel,
 // k = (tap, channel of the (possibly two-source) input).  Wp is the packed weight [N][K].

@@ -123,7 +123,7 @@ class DDIMSampler(object):
         if verbose:
             print(f"Running DDIM Sampling with {total_steps} timesteps")
         iterator = tqdm(time_range, desc='DDIM Sampler', total=total_steps, disable=not verbose)
-        st = self._StepState(self, img, u_cond)
+        st = self._state_for(img, u_cond)
         for i, step in enumerate(iterator):
             index = total_steps - i - 1
             if mask is not None:
@@ -142,6 +142,19 @@ class DDIMSampler(object):
             if img_callback:
                 img_callback(pred_x0, i)
         return st.x().clone(), intermediates
+
+    def _state_for(self, img, doubled):
+        """Loop buffers are kept per (shape, doubled) so that repeated calls present the same device
+        addresses to the UNet (its captured launch graph is then replayed instead of re-recorded)."""
+        cache = self.__dict__.setdefault("_states", {})
+        key = (tuple(img.shape), bool(doubled), str(self.model.device))
+        st = cache.get(key)
+        if st is None:
+            st = cache[key] = self._StepState(self, img, doubled)
+        else:
+            st.set_x(img.to(self.model.device, torch.float32))
+            st.t_val = None
+        return st
 
     class _StepState:
         """Persistent device buffers for a sampling loop: the (possibly doubled) UNet input, the
@@ -246,7 +259,7 @@ class DDIMSampler(object):
             print(f"Running DDIM Sampling with {total_steps} timesteps")
         doubled = bool(unconditional_conditioning is not None and unconditional_conditioning is not False) \
             and unconditional_guidance_scale != 1.
-        st = self._StepState(self, x_latent, doubled)
+        st = self._state_for(x_latent, doubled)
         for i, step in enumerate(tqdm(time_range, desc='Decoding image', total=total_steps, disable=not verbose)):
             index = total_steps - i - 1
             st.step(cond, int(step), index, use_original_steps=use_original_steps,

@@ -1,9 +1,318 @@
-// Attention dispatcher (the MFMA flash kernel is added below as it lands).
+// Flash-style attention on the gfx950 matrix cores (fp16 / bf16 operands, fp32 accumulation and
+// softmax statistics); the score matrix never leaves registers.
+//
+// Work split: one workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries.
+// K/V are walked in tiles of 64 keys, staged global -> registers -> LDS (two LDS buffers, the loads
+// of tile t+1 are issued before the MFMAs of tile t and written after them; one barrier per tile).
+//
+// Per tile and wave, with v_mfma_f32_32x32x16:
+//   S^T = K Q^T   (A = K rows from LDS by ds_read_b128, B = the wave's Q fragments, kept in registers
+//                  for the whole kernel) -> a lane holds, for ITS query (lane & 31), 16 of the 32 keys
+//                  of a 32-key block, the other 16 sit in lane ^ 32: the softmax row statistics need
+//                  one cross-half exchange per tile and no LDS;
+//   P^T          = exp2(S^T * c - m) converted to 16 bit in place: the accumulator registers 8s..8s+7
+//                  are exactly the B operand of k-step s of the next product (k order permuted, so
+//                  the other operand is fetched in the same order);
+//   O^T += V^T P^T (A = V^T read from the row-major V tile with ds_read_b64_tr_b16, the hardware
+//                  transpose read) -> the output accumulator has the query on the lane as well, so the
+//                  running-max rescale is a per-lane scalar multiply.
+// Head sizes that are not multiples of 16 / 32 (40, 80) are zero-padded in the Q fragments only; K rows
+// stay unpadded in LDS (row stride = odd multiple of 16 bytes => conflict-free ds_read_b128) and the V
+// row stride is 64 or 192 (mod 256) bytes so the four key rows of a transpose read hit disjoint banks.
 #include "ops.h"
 
 int attention_scalar(const AttentionArgs& a, hipStream_t stream);
+int attention_init();
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mfma32;
+template <> struct Mfma32<half_t> {
+  typedef half_t v8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ f32x16 mma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mfma32<bf16_t> {
+  typedef bf16_t v8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ f32x16 mma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+struct FlashParams {
+  const char* q; const char* k; const char* v; char* out;
+  int ldq, ldk, ldv, ldo;      // in elements
+  int B, heads, Nq, Nk;
+  float c;                     // scale * log2(e)
+};
+
+constexpr int KV_TILE = 64;
+
+template <int D> struct Geo {
+  static constexpr int KSTEPS = (D + 15) / 16;            // 16-wide contraction steps of K Q^T
+  static constexpr int DT = (D + 31) / 32;                // 32-row output tiles of V^T P^T
+  static constexpr int CPR = D / 8;                       // 16-byte chunks per K/V row
+  static constexpr int NCH = KV_TILE * CPR;               // chunks per tile
+  static constexpr int KC = (NCH + 255) / 256;            // chunks per thread
+  static constexpr int SK = ((D * 2 + 15) / 16 * 16) | 16;    // K row stride: odd multiple of 16 B
+  static constexpr int sv_min = DT * 64;                  // bytes the transpose reads touch per row
+  static constexpr int SV = (sv_min <= 64) ? 64 : (sv_min <= 192 ? 192 : (sv_min <= 320 ? 320 : (sv_min <= 448 ? 448 : 576)));
+  static constexpr int KBUF = KV_TILE * SK + 32;          // + zeroed tail for the last row's over-read
+  static constexpr int VBUF = KV_TILE * SV;
+  static constexpr int STAGE = KBUF + VBUF;
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_flash_kernel(FlashParams p) {
+  typedef Geo<D> G;
+  typedef typename Mfma32<T>::v8 v8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / p.heads, hd = bh - b * p.heads;
+  const int qi = blockIdx.x * 128 + wid * 32 + r;
+  const int qrow = min(qi, p.Nq - 1);
+
+  // ---- Q fragments (B operand of K Q^T): dims 16s + 8h .. +7 of this lane's query ---------------
+  v8 qf[G::KSTEPS];
+  {
+    const char* qp = p.q + ((size_t)((size_t)b * p.Nq + qrow) * p.ldq + (size_t)hd * D) * sizeof(T);
+#pragma unroll
+    for (int s = 0; s < G::KSTEPS; ++s) {
+      const int d0 = 16 * s + 8 * h;
+      if (d0 < D) qf[s] = *reinterpret_cast<const v8*>(qp + d0 * sizeof(T));
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[s][e] = (T)0.f;
+      }
+    }
+  }
+
+  // ---- K/V staging -----------------------------------------------------------------------------
+  u32x4 kreg[G::KC], vreg[G::KC];
+  const char* kbase = p.k + ((size_t)b * p.Nk * p.ldk + (size_t)hd * D) * sizeof(T);
+  const char* vbase = p.v + ((size_t)b * p.Nk * p.ldv + (size_t)hd * D) * sizeof(T);
+  // chunk geometry of this thread (clamped so every staging register is always written)
+  int ch_key[G::KC], ch_piece[G::KC];
+  bool ch_ok[G::KC];
+#pragma unroll
+  for (int i = 0; i < G::KC; ++i) {
+    const int c = tid + i * 256;
+    ch_ok[i] = c < G::NCH;
+    const int cc = ch_ok[i] ? c : G::NCH - 1;
+    ch_key[i] = cc / G::CPR;
+    ch_piece[i] = cc - ch_key[i] * G::CPR;
+  }
+#define LOAD_TILE(t_)                                                                                     \
+  _Pragma("unroll") for (int i = 0; i < G::KC; ++i) {                                                     \
+    const int row = min((t_) * KV_TILE + ch_key[i], p.Nk - 1);                                            \
+    kreg[i] = *reinterpret_cast<const u32x4*>(kbase + ((size_t)row * p.ldk + ch_piece[i] * 8) * sizeof(T)); \
+    vreg[i] = *reinterpret_cast<const u32x4*>(vbase + ((size_t)row * p.ldv + ch_piece[i] * 8) * sizeof(T)); \
+  }
+#define STORE_TILE(buf_)                                                                                  \
+  {                                                                                                       \
+    char* kb_ = smem + (buf_) * G::STAGE;                                                                 \
+    char* vb_ = kb_ + G::KBUF;                                                                            \
+    _Pragma("unroll") for (int i = 0; i < G::KC; ++i) {                                                   \
+      if (ch_ok[i]) {                                                                                     \
+        *reinterpret_cast<u32x4*>(kb_ + ch_key[i] * G::SK + ch_piece[i] * 16) = kreg[i];                  \
+        *reinterpret_cast<u32x4*>(vb_ + ch_key[i] * G::SV + ch_piece[i] * 16) = vreg[i];                  \
+      }                                                                                                   \
+    }                                                                                                     \
+  }
+  // zero the over-read tails of both K buffers once (finite operands for the zero-padded Q dims)
+  if (tid < 4) {
+    const int buf = tid >> 1, part = tid & 1;
+    *reinterpret_cast<u32x4*>(smem + buf * G::STAGE + KV_TILE * G::SK + part * 16) = (u32x4){0u, 0u, 0u, 0u};
+  }
+
+  f32x16 o[G::DT];
+#pragma unroll
+  for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (p.Nk + KV_TILE - 1) / KV_TILE;
+  LOAD_TILE(0)
+  STORE_TILE(0)
+  __syncthreads();
+
+  // transpose-read lane geometry: 16-lane group g covers d columns (g&1)*16.., key rows 4*(g>>1)..;
+  // lane i of the group supplies the address of key row i>>2, columns 4*(i&3)..
+  const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gcol = ((lane >> 4) & 1) * 16 + gp * 4;
+
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) { LOAD_TILE(t + 1) }
+    const char* kb = smem + (t & 1) * G::STAGE;
+    const char* vb = kb + G::KBUF;
+
+    // ---- S^T = K Q^T for the two 32-key blocks ---------------------------------------------------
+    f32x16 s0, s1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < G::KSTEPS; ++s) {
+      const v8 a0 = *reinterpret_cast<const v8*>(kb + r * G::SK + s * 32 + h * 16);
+      const v8 a1 = *reinterpret_cast<const v8*>(kb + (32 + r) * G::SK + s * 32 + h * 16);
+      s0 = Mfma32<T>::mma(a0, qf[s], s0);
+      s1 = Mfma32<T>::mma(a1, qf[s], s1);
+    }
+    if (t == ntiles - 1 && (p.Nk & (KV_TILE - 1)) != 0) {
+      const int kbase_i = t * KV_TILE + 4 * h;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = kbase_i + (i & 3) + 8 * (i >> 2);
+        if (key >= p.Nk) s0[i] = -INFINITY;
+        if (key + 32 >= p.Nk) s1[i] = -INFINITY;
+      }
+    }
+
+    // ---- online softmax (per lane = per query; partner lane ^ 32 holds the other keys) ----------
+    float mx = s0[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s0[i]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s1[i]);
+    mx *= p.c;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    l_run *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+    v8 pf[4];        // P^T fragments: block 0 k-steps 0,1 then block 1 k-steps 0,1
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float e0 = __builtin_amdgcn_exp2f(fmaf(s0[i], p.c, -m_new));
+      const float e1 = __builtin_amdgcn_exp2f(fmaf(s1[i], p.c, -m_new));
+      l_run += e0 + e1;
+      pf[i >> 3][i & 7] = (T)e0;
+      pf[2 + (i >> 3)][i & 7] = (T)e1;
+    }
+
+    // ---- O^T += V^T P^T ---------------------------------------------------------------------------
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int key0 = (f >> 1) * 32 + (f & 1) * 16 + 4 * h + gq;      // first 4-key block; second is +8
+#pragma unroll
+      for (int dt = 0; dt < G::DT; ++dt) {
+        const char* a0p = vb + key0 * G::SV + (dt * 32 + gcol) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0p);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(a0p + 8 * G::SV));
+        s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        o[dt] = Mfma32<T>::mma(__builtin_bit_cast(v8, both), pf[f], o[dt]);
+      }
+    }
+
+    if (t + 1 < ntiles) STORE_TILE((t + 1) & 1)
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds d = 32 dt + 8 (i>>2) + 4 h + (i&3) of its query --------------
+  l_run += __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_run;
+  if (qi < p.Nq) {
+    char* op = p.out + ((size_t)((size_t)b * p.Nq + qi) * p.ldo + (size_t)hd * D) * sizeof(T);
+    typedef T Tx4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d0 = dt * 32 + 8 * g4 + 4 * h;
+        if (d0 < D) {
+          Tx4 v = {(T)(o[dt][g4 * 4 + 0] * inv), (T)(o[dt][g4 * 4 + 1] * inv), (T)(o[dt][g4 * 4 + 2] * inv),
+                   (T)(o[dt][g4 * 4 + 3] * inv)};
+          *reinterpret_cast<Tx4*>(op + d0 * sizeof(T)) = v;
+        }
+      }
+  }
+}
+
+#undef LOAD_TILE
+#undef STORE_TILE
+
+template <typename T, int D>
+int launch_flash(const AttentionArgs& a, hipStream_t stream) {
+  typedef Geo<D> G;
+  static_assert(D % 8 == 0 && G::DT * 64 <= G::SV && D * 2 <= G::SV, "bad head size geometry");
+  FlashParams p;
+  p.q = (const char*)a.q; p.k = (const char*)a.k; p.v = (const char*)a.v; p.out = (char*)a.out;
+  p.ldq = a.ldq; p.ldk = a.ldk; p.ldv = a.ldv; p.ldo = a.ldo;
+  p.B = a.B; p.heads = a.heads; p.Nq = a.Nq; p.Nk = a.Nk;
+  p.c = a.scale * 1.4426950408889634f;
+  const int lds = 2 * G::STAGE;
+  dim3 grid((a.Nq + 127) / 128, a.B * a.heads);
+  hipLaunchKernelGGL((attn_flash_kernel<T, D>), grid, dim3(256), lds, stream, p);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+template <typename T>
+int dispatch_flash(const AttentionArgs& a, hipStream_t stream, bool* handled) {
+  *handled = true;
+  switch (a.d) {
+    case 40: return launch_flash<T, 40>(a, stream);
+    case 64: return launch_flash<T, 64>(a, stream);
+    case 80: return launch_flash<T, 80>(a, stream);
+    case 128: return launch_flash<T, 128>(a, stream);
+    case 160: return launch_flash<T, 160>(a, stream);
+    default: *handled = false; return SDMI_OK;
+  }
+}
+
+}  // namespace
 
 int attention(const AttentionArgs& a, hipStream_t stream) {
+  SDMI_REQUIRE(a.q && a.k && a.v && a.out, "attention: null pointer");
+  SDMI_REQUIRE(a.B > 0 && a.heads > 0 && a.Nq > 0 && a.Nk > 0 && a.d > 0, "attention: empty problem");
   ProfScope prof(PROF_ATTENTION, stream, 4.0 * a.B * a.heads * (double)a.Nq * a.Nk * a.d, 0.0);
+  if (a.impl != 1 && a.dtype != SDMI_F32) {
+    SDMI_TRY(attention_init());
+    SDMI_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 4 == 0,
+                 "attention: row strides must be multiples of 8 elements");
+    bool handled = false;
+    int rc;
+    if (a.dtype == SDMI_F16) rc = dispatch_flash<half_t>(a, stream, &handled);
+    else rc = dispatch_flash<bf16_t>(a, stream, &handled);
+    if (handled) return rc;
+  }
   return attention_scalar(a, stream);
+}
+
+namespace {
+template <typename T, int D>
+int init_one() {
+  const int lds = 2 * Geo<D>::STAGE;
+  if (lds > 48 * 1024)
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_flash_kernel<T, D>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  return SDMI_OK;
+}
+template <typename T>
+int init_all() {
+  SDMI_TRY((init_one<T, 40>())); SDMI_TRY((init_one<T, 64>())); SDMI_TRY((init_one<T, 80>()));
+  SDMI_TRY((init_one<T, 128>())); SDMI_TRY((init_one<T, 160>()));
+  return SDMI_OK;
+}
+}  // namespace
+
+// Raise dynamic-LDS limits once, outside of stream capture (called from finalize and lazily).
+int attention_init() {
+  static bool done = false;
+  if (done) return SDMI_OK;
+  SDMI_TRY(init_all<half_t>());
+  SDMI_TRY(init_all<bf16_t>());
+  done = true;
+  return SDMI_OK;
 }

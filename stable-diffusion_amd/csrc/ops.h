@@ -80,6 +80,7 @@ struct AttentionArgs {
   int impl = 0;                           // 0 = auto, 1 = force the scalar (fp32-math) kernel
 };
 int attention(const AttentionArgs& a, hipStream_t stream);
+int attention_init();   // one-time kernel attribute setup; call outside stream capture
 
 // ---- small / elementwise ---------------------------------------------------------------------
 // emb[b][:] = [cos(t*f) | sin(t*f)], f_k = exp(-ln(max_period) k / half)            (fp32 out)

@@ -1,12 +1,13 @@
 // GroupNorm(+SiLU) and LayerNorm for NHWC / token-major activations on gfx950.  HBM-bound kernels:
 // 16-byte vector loads/stores, fp32 statistics, double-precision combination of partial sums.
 //
-// GroupNorm runs as three launches:
-//   1. gn_partial : grid (chunks, B); every thread owns one 16-byte channel vector and walks a strip
+// GroupNorm runs as two launches:
+//   1. gn_partial : grid (strips, B); every thread owns one 16-byte channel vector and walks a strip
 //                   of pixels, keeping per-channel sum / sum-of-squares in registers; the block folds
-//                   them into per-group partial sums in LDS and writes [B][chunk][G][2] floats.
-//   2. gn_finalize: one thread per (b, group): combines the chunk partials in double -> mean, rstd.
-//   3. gn_apply   : elementwise normalise * gamma + beta (+ SiLU), 16 bytes per thread.
+//                   them into per-group partial sums in LDS (fixed order) and writes [B][strip][G][2].
+//   2. gn_apply   : same grid; each block combines the strip partials of its sample in double ->
+//                   mean, rstd, then normalises its strip with per-thread precomputed scale/shift
+//                   (+ SiLU), 16-byte loads and stores.
 // The input may be the channel-concatenation of two tensors (UNet skip connections); groups may
 // straddle the seam, which is why statistics are accumulated per channel first.
 #include "ops.h"
@@ -45,33 +46,60 @@ struct GnParams {
 
 constexpr int GN_LDS_SLOTS = 1024;   // >= max(blockDim, C / elements-per-vector)
 
+// Thread layout shared by both kernels: blockDim = nvec * lanes_pix when one pixel's vectors fit a
+// block (a thread owns ONE channel vector and walks every lanes_pix-th pixel of the block's strip);
+// wider tensors make a thread stride over vectors and take every pixel.
+struct GnLayout {
+  int nvec, lanes_pix, pix_lane, vstride, v_first, p_begin, p_end;
+};
+template <int EPV>
+__device__ __forceinline__ GnLayout gn_layout(const GnParams& p, int chunk) {
+  GnLayout L;
+  L.nvec = p.C / EPV;
+  const bool fits = (int)blockDim.x >= L.nvec;
+  L.lanes_pix = fits ? (int)blockDim.x / L.nvec : 1;
+  L.pix_lane = fits ? (int)threadIdx.x / L.nvec : 0;
+  L.vstride = fits ? L.nvec : (int)blockDim.x;
+  L.v_first = fits ? (int)threadIdx.x - L.pix_lane * L.nvec : (int)threadIdx.x;
+  L.p_begin = chunk * p.pix_per_chunk;
+  L.p_end = min(p.HW, L.p_begin + p.pix_per_chunk);
+  return L;
+}
+
 template <typename T>
-__global__ void gn_partial_kernel(GnParams p) {
+__global__ __launch_bounds__(256) void gn_partial_kernel(GnParams p) {
   constexpr int EPV = VecOf<T>::N;
   // per-(pixel lane, vector) partial sums: [0]=sum,[1]=sumsq of the vector's first group, [2],[3] of
   // its second group (a 16-byte vector spans at most two groups)
   __shared__ float ls[4][GN_LDS_SLOTS];
-  const int nvec = p.C / EPV;
   const int chunk = blockIdx.x, b = blockIdx.y;
-  // blockDim is nvec * lanes_pix when the vectors of one pixel fit a block (every thread owns one
-  // vector and every lanes_pix-th pixel); otherwise a thread strides over vectors and takes all pixels.
-  const bool fits = (int)blockDim.x >= nvec;
-  const int lanes_pix = fits ? (int)blockDim.x / nvec : 1;
-  const int pix_lane = fits ? (int)threadIdx.x / nvec : 0;
-  const int vstride = fits ? nvec : (int)blockDim.x;
-  const int p_begin = chunk * p.pix_per_chunk;
-  const int p_end = min(p.HW, p_begin + p.pix_per_chunk);
-  for (int v = fits ? (int)threadIdx.x % nvec : (int)threadIdx.x; v < nvec; v += vstride) {
+  const GnLayout L = gn_layout<EPV>(p, chunk);
+  for (int v = L.v_first; v < L.nvec; v += L.vstride) {
     const int c = v * EPV;
     const T* src; int cs, cc;
     if (c < p.c0) { src = (const T*)p.x0; cs = p.c0; cc = c; }
     else { src = (const T*)p.x1; cs = p.c1; cc = c - p.c0; }
+    src += (size_t)b * p.HW * cs + cc;
     float s[EPV], q[EPV];
 #pragma unroll
     for (int e = 0; e < EPV; ++e) { s[e] = 0.f; q[e] = 0.f; }
-    for (int px = p_begin + pix_lane; px < p_end; px += lanes_pix) {
+    int px = L.p_begin + L.pix_lane;
+    // four independent 16-byte loads in flight per thread
+    for (; px + 3 * L.lanes_pix < L.p_end; px += 4 * L.lanes_pix) {
+      float f0[EPV], f1[EPV], f2[EPV], f3[EPV];
+      load_vec<T>(src + (size_t)px * cs, f0);
+      load_vec<T>(src + (size_t)(px + L.lanes_pix) * cs, f1);
+      load_vec<T>(src + (size_t)(px + 2 * L.lanes_pix) * cs, f2);
+      load_vec<T>(src + (size_t)(px + 3 * L.lanes_pix) * cs, f3);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        s[e] += (f0[e] + f1[e]) + (f2[e] + f3[e]);
+        q[e] += (f0[e] * f0[e] + f1[e] * f1[e]) + (f2[e] * f2[e] + f3[e] * f3[e]);
+      }
+    }
+    for (; px < L.p_end; px += L.lanes_pix) {
       float f[EPV];
-      load_vec<T>(src + ((size_t)b * p.HW + px) * cs + cc, f);
+      load_vec<T>(src + (size_t)px * cs, f);
 #pragma unroll
       for (int e = 0; e < EPV; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
     }
@@ -81,7 +109,7 @@ __global__ void gn_partial_kernel(GnParams p) {
     for (int e = 0; e < EPV; ++e) {
       if (c + e < boundary) { sa += s[e]; qa += q[e]; } else { sb += s[e]; qb += q[e]; }
     }
-    const int slot = pix_lane * nvec + v;
+    const int slot = L.pix_lane * L.nvec + v;
     ls[0][slot] = sa; ls[1][slot] = qa; ls[2][slot] = sb; ls[3][slot] = qb;
   }
   __syncthreads();
@@ -90,9 +118,9 @@ __global__ void gn_partial_kernel(GnParams p) {
     const int g = threadIdx.x;
     const int v_lo = (g * p.cpg) / EPV, v_hi = ((g + 1) * p.cpg - 1) / EPV;
     float s = 0.f, q = 0.f;
-    for (int pl = 0; pl < lanes_pix; ++pl)
+    for (int pl = 0; pl < L.lanes_pix; ++pl)
       for (int v = v_lo; v <= v_hi; ++v) {
-        const int slot = pl * nvec + v;
+        const int slot = pl * L.nvec + v;
         const int g0 = (v * EPV) / p.cpg;
         if (g0 == g) { s += ls[0][slot]; q += ls[1][slot]; }
         else { s += ls[2][slot]; q += ls[3][slot]; }
@@ -103,54 +131,82 @@ __global__ void gn_partial_kernel(GnParams p) {
   }
 }
 
-__global__ void gn_finalize_kernel(GnParams p) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= p.B * p.groups) return;
-  const int b = idx / p.groups, g = idx - b * p.groups;
-  double s = 0.0, q = 0.0;
-  for (int c = 0; c < p.chunks; ++c) {
-    const float* src = p.partial + (((size_t)b * p.chunks + c) * p.groups + g) * 2;
-    s += (double)src[0]; q += (double)src[1];
-  }
-  const double n = (double)p.cpg * (double)p.HW;
-  const double mean = s / n;
-  double var = q / n - mean * mean;
-  if (var < 0.0) var = 0.0;
-  p.stats[idx * 2 + 0] = (float)mean;
-  p.stats[idx * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
-}
-
+// Second pass: every block first folds the chunk partials of its sample into (mean, rstd) per group
+// (8 slices per group in parallel, combined in double in a fixed order), then normalises its strip
+// with per-thread precomputed scale/shift: y = x * (rstd*gamma) + (beta - mean*rstd*gamma) [+ SiLU].
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnParams p) {
   constexpr int EPV = VecOf<T>::N;
-  const int nvec = p.C / EPV;
-  const size_t total = (size_t)p.B * p.HW * nvec;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * blockDim.x) {
-    const size_t pix = idx / nvec;                 // b*HW + px
-    const int v = (int)(idx - pix * nvec);
-    const int b = (int)(pix / p.HW);
+  __shared__ double red[2][8][64];
+  __shared__ float s_mean[64], s_rstd[64];
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  {
+    const int t = threadIdx.x;
+    for (int u = t; u < 8 * p.groups; u += (int)blockDim.x) {
+      const int g = u % p.groups, slice = u / p.groups;
+      double s = 0.0, q = 0.0;
+      for (int c = slice; c < p.chunks; c += 8) {
+        const float* src = p.partial + (((size_t)b * p.chunks + c) * p.groups + g) * 2;
+        s += (double)src[0]; q += (double)src[1];
+      }
+      red[0][slice][g] = s; red[1][slice][g] = q;
+    }
+    __syncthreads();
+    if (t < p.groups) {
+      double s = 0.0, q = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s += red[0][k][t]; q += red[1][k][t]; }
+      const double n = (double)p.cpg * (double)p.HW;
+      const double mean = s / n;
+      double var = q / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_mean[t] = (float)mean;
+      s_rstd[t] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    __syncthreads();
+  }
+  const GnLayout L = gn_layout<EPV>(p, chunk);
+  for (int v = L.v_first; v < L.nvec; v += L.vstride) {
     const int c = v * EPV;
     const T* src; int cs, cc;
     if (c < p.c0) { src = (const T*)p.x0; cs = p.c0; cc = c; }
     else { src = (const T*)p.x1; cs = p.c1; cc = c - p.c0; }
-    float f[EPV];
-    load_vec<T>(src + pix * cs + cc, f);
+    src += (size_t)b * p.HW * cs + cc;
+    T* dst = (T*)p.out + (size_t)b * p.HW * p.C + c;
     const int g0 = c / p.cpg;
     const int boundary = (g0 + 1) * p.cpg;
-    const float* st = p.stats + ((size_t)b * p.groups + g0) * 2;
-    const float m0 = st[0], r0 = st[1];
-    float m1 = m0, r1 = r0;
-    if (boundary < c + EPV) { m1 = st[2]; r1 = st[3]; }
+    float sc[EPV], sh[EPV];
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
-      const bool first = c + e < boundary;
-      float y = (f[e] - (first ? m0 : m1)) * (first ? r0 : r1);
-      y = y * p.gamma[c + e] + p.beta[c + e];
-      if (p.silu) y = silu_f(y);
-      f[e] = y;
+      const int g = (c + e < boundary) ? g0 : g0 + 1;
+      const float rg = s_rstd[g] * p.gamma[c + e];
+      sc[e] = rg;
+      sh[e] = p.beta[c + e] - s_mean[g] * rg;
     }
-    store_vec<T>((T*)p.out + pix * p.C + c, f);
+    int px = L.p_begin + L.pix_lane;
+    for (; px + L.lanes_pix < L.p_end; px += 2 * L.lanes_pix) {
+      float f0[EPV], f1[EPV];
+      load_vec<T>(src + (size_t)px * cs, f0);
+      load_vec<T>(src + (size_t)(px + L.lanes_pix) * cs, f1);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        f0[e] = fmaf(f0[e], sc[e], sh[e]);
+        f1[e] = fmaf(f1[e], sc[e], sh[e]);
+        if (p.silu) { f0[e] = silu_f(f0[e]); f1[e] = silu_f(f1[e]); }
+      }
+      store_vec<T>(dst + (size_t)px * p.C, f0);
+      store_vec<T>(dst + (size_t)(px + L.lanes_pix) * p.C, f1);
+    }
+    for (; px < L.p_end; px += L.lanes_pix) {
+      float f[EPV];
+      load_vec<T>(src + (size_t)px * cs, f);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        f[e] = fmaf(f[e], sc[e], sh[e]);
+        if (p.silu) f[e] = silu_f(f[e]);
+      }
+      store_vec<T>(dst + (size_t)px * p.C, f);
+    }
   }
 }
 
@@ -161,29 +217,30 @@ int launch_gn(const GroupNormArgs& a, hipStream_t stream) {
   p.x0 = a.x0; p.x1 = a.x1; p.c0 = a.c0; p.c1 = a.x1 ? a.c1 : 0; p.C = p.c0 + p.c1;
   p.B = a.B; p.HW = a.HW; p.groups = a.groups;
   SDMI_REQUIRE(a.x0 && a.out && a.gamma && a.beta && a.scratch, "groupnorm: null pointer");
-  SDMI_REQUIRE(p.groups > 0 && p.groups <= 64 && p.C % p.groups == 0, "groupnorm: C=%d groups=%d", p.C, p.groups);
+  SDMI_REQUIRE(p.groups > 0 && p.groups <= 32 && p.C % p.groups == 0, "groupnorm: C=%d groups=%d", p.C, p.groups);
   p.cpg = p.C / p.groups;
   SDMI_REQUIRE(p.c0 % EPV == 0 && p.c1 % EPV == 0, "groupnorm: channels must be multiples of %d", EPV);
   SDMI_REQUIRE(p.cpg >= EPV || 2 * p.cpg == EPV || p.cpg == EPV,
                "groupnorm: a %d-element vector may span at most two groups (cpg=%d)", EPV, p.cpg);
   SDMI_REQUIRE(p.B > 0 && p.HW > 0, "groupnorm: empty input");
   p.eps = a.eps; p.gamma = a.gamma; p.beta = a.beta; p.silu = a.silu; p.out = a.out;
-  int chunks = (p.HW + 63) / 64;
+  const int nvec = p.C / EPV;
+  SDMI_REQUIRE(nvec <= GN_LDS_SLOTS, "groupnorm: C=%d too wide", p.C);
+  const int threads = nvec <= 256 ? nvec * (256 / nvec) : 256;
+  const int lanes_pix = nvec <= 256 ? 256 / nvec : 1;
+  // enough strips to fill the chip (>= ~2048 blocks in all), each at least 4 pixels per pixel lane
+  int chunks = (2048 + p.B - 1) / p.B;
+  const int max_by_work = (p.HW + 4 * lanes_pix - 1) / (4 * lanes_pix);
+  if (chunks > max_by_work) chunks = max_by_work;
   if (chunks > GN_MAX_CHUNKS) chunks = GN_MAX_CHUNKS;
+  if (chunks < 1) chunks = 1;
   p.pix_per_chunk = (p.HW + chunks - 1) / chunks;
   p.chunks = (p.HW + p.pix_per_chunk - 1) / p.pix_per_chunk;
   p.partial = a.scratch;
-  p.stats = a.scratch + (size_t)p.B * GN_MAX_CHUNKS * p.groups * 2;
-  const int nvec = p.C / EPV;
-  SDMI_REQUIRE(nvec <= GN_LDS_SLOTS, "groupnorm: C=%d too wide", p.C);
-  int threads = nvec <= 256 ? nvec * (256 / nvec) : 256;
+  p.stats = nullptr;
   ProfScope prof(PROF_GROUPNORM, stream, 0.0, 2.0 * p.B * (double)p.HW * p.C * sizeof(T));
   hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(p.chunks, p.B), dim3(threads), 0, stream, p);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((p.B * p.groups + 63) / 64), dim3(64), 0, stream, p);
-  const size_t total = (size_t)p.B * p.HW * nvec;
-  size_t blocks = (total + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(gn_apply_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(p.chunks, p.B), dim3(threads), 0, stream, p);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

@@ -10,15 +10,14 @@ nothing until the decoded images are all-gathered (RCCL) at the end.
 """
 import torch
 
-from . import ops, synth
-from .ddim import DDIMSampler
-from .ddpm import LatentDiffusion
+from . import synth
 from .structure import sd_v1_model_params
 
 
 def build_synthetic_model(in_channels=4, conditioning_key="crossattn", dtype="fp16", seed=0, device="cuda"):
     """LatentDiffusion with SD-v1-shaped weights from the deterministic synthesiser (no checkpoint
     exists offline).  Hash keys are the un-prefixed checkpoint names."""
+    from .ddpm import LatentDiffusion
     params = sd_v1_model_params(in_channels, conditioning_key)
     model = LatentDiffusion(**params, compute_dtype=dtype, device=device)
     sd = {"model.diffusion_model." + k: synth.synth_tensor(seed, k, s, device)
@@ -45,6 +44,8 @@ def initial_latents(batch, h, w, device="cuda", first_sample=0, seed=42):
 @torch.no_grad()
 def txt2img(model, x_T, uc, c, steps=50, scale=7.5, eta=0.0, sampler=None):
     """One batch through the whole path; returns images (B,3,8h,8w) in [0,1] and the final latents."""
+    from . import ops
+    from .ddim import DDIMSampler
     sampler = sampler or DDIMSampler(model)
     b, _, h, w = x_T.shape
     cond = torch.cat([uc, c]) if scale != 1.0 else c
@@ -70,5 +71,8 @@ def gather_images(img, world=None):
         return img
     world = dist.get_world_size()
     out = torch.empty((world * img.shape[0],) + tuple(img.shape[1:]), dtype=img.dtype, device=img.device)
-    dist.all_gather_into_tensor(out, img.contiguous())
+    try:
+        dist.all_gather_into_tensor(out, img.contiguous())
+    except (RuntimeError, NotImplementedError):       # backends without the flat variant
+        dist.all_gather(list(out.chunk(world)), img.contiguous())
     return out

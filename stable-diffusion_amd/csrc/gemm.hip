@@ -24,14 +24,25 @@
 // can be split over blockIdx.y; partial sums go to an fp32 slab and a second kernel reduces them
 // and applies the epilogue.
 #include "ops.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, NTHREADS = 256;
-constexpr int TILE_BYTES = 128 * 128;           // one operand tile in LDS
-constexpr int LDS_BYTES = 4 * TILE_BYTES;       // 2 buffers x (A + W)
+// Block shapes: WM x WN waves, each wave owns a 64x64 output tile; NSTAGE LDS stages of
+// (BM + BN) rows x 128 bytes.  The DMA of tile k+NSTAGE-1 is issued while tile k is multiplied.
+template <int WM_, int WN_, int NSTAGE_> struct Shape {
+  static constexpr int WM = WM_, WN = WN_, NSTAGE = NSTAGE_;
+  static constexpr int NW = WM * WN, NTHREADS = 64 * NW;
+  static constexpr int BM = 64 * WM, BN = 64 * WN;
+  static constexpr int AP = (BM / 8) / NW, WP = (BN / 8) / NW;     // 1-KiB DMA pieces per wave and tile
+  static constexpr int GL = AP + WP;                                // global_load_lds per wave and tile
+  static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
+  static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must divide evenly over the waves");
+};
+typedef Shape<2, 2, 2> ShapeSmall;      // 128x128, 4 waves, 64 KiB: two blocks per CU (small-M layers)
+typedef Shape<4, 2, 3> ShapeLarge;      // 256x128, 8 waves, 144 KiB: one block per CU, two tiles in flight
 
-__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];   // never written
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -44,6 +55,8 @@ struct GemmParams {
   int nkt, kt_per_split;
   float* partial;
   int tiles_m, tiles_n;
+  const char* zero;   // 256 zero bytes (halo / out-of-range rows read these)
+  int dbg;   // timing experiments only: bit0 = activation loads hit the zero page, bit1 = weight loads
 };
 
 template <typename T> struct Frag;      // 16 bytes of T as an MFMA operand fragment
@@ -113,16 +126,17 @@ __device__ __forceinline__ void epilogue_store_geglu(const GemmParams& p, int m,
   *reinterpret_cast<Tx4*>(o) = ov;
 }
 
-template <typename T>
-__global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(GemmParams p) {
+template <typename T, typename S>
+__global__ __launch_bounds__(S::NTHREADS) void conv_gemm_kernel(GemmParams p) {
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
   constexpr int BK = 8 * EPC;                // k elements per tile row (128 bytes)
+  constexpr int BM = S::BM, BN = S::BN, AP = S::AP, WP = S::WP, NSTAGE = S::NSTAGE;
   typedef typename Frag<T>::type frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / S::WN, wn = wid - wm * S::WN;
 
   // XCD-aware tile order: workgroups dealt to the same XCD (bid % 8) take a contiguous range of
   // tile ids, n fastest, so that they share A panels and keep the weight panel in that XCD's L2.
@@ -138,46 +152,52 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(GemmParams p) {
   const int kt_begin = blockIdx.y * p.kt_per_split;
   const int kt_end = min(p.nkt, kt_begin + p.kt_per_split);
 
-  // ---- loader state: 4 activation rows + 4 weight rows per thread ---------------------------
+  // ---- loader state: AP activation rows + WP weight rows per thread ---------------------------
   const int lrow = lane >> 3;                        // row within an 8-row DMA piece
   const int sc = (lane & 7) ^ lrow;                  // swizzled source chunk for LDS chunk lane&7
   const int hw = p.Ho * p.Wo;
-  int a_b[4], a_oy[4], a_ox[4];
-  bool a_ok[4];
-  const char* wptr[4];
-  int wstep[4];
+  const bool pointwise = (p.taps == 1 && p.stride == 1 && !p.up);
+  int a_b[AP], a_oy[AP], a_ox[AP];
+  bool a_ok[AP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (wid * 4 + i) * 8 + lrow;
-    const int m = m0 + r;
+  for (int i = 0; i < AP; ++i) {
+    const int m = m0 + (wid * AP + i) * 8 + lrow;
     a_ok[i] = m < p.M;
     const int mm = a_ok[i] ? m : 0;
-    if (p.taps == 1 && p.stride == 1 && !p.up) {
+    if (pointwise) {
       a_b[i] = 0; a_oy[i] = 0; a_ox[i] = mm;          // pointwise: pixel index = row index
     } else {
       const int b = mm / hw, rem = mm - b * hw;
       a_b[i] = b; a_oy[i] = rem / p.Wo; a_ox[i] = rem - (rem / p.Wo) * p.Wo;
     }
-    const int n = n0 + r;
-    const bool wok = n < p.N;
-    wptr[i] = wok ? p.w + ((size_t)n * p.K) * sizeof(T) + sc * 16 : (const char*)g_zero_page + sc * 16;
+  }
+  const char* wptr[WP];
+  int wstep[WP];
+#pragma unroll
+  for (int i = 0; i < WP; ++i) {
+    const int n = n0 + (wid * WP + i) * 8 + lrow;
+    const bool wok = n < p.N && !(p.dbg & 2);
+    wptr[i] = wok ? p.w + ((size_t)n * p.K) * sizeof(T) + sc * 16 : p.zero + sc * 16;
     wstep[i] = wok ? 128 : 0;
   }
-  const bool pointwise = (p.taps == 1 && p.stride == 1 && !p.up);
   const int tiles_c0 = p.c0 / BK, tiles_c1 = p.c1 / BK, tiles_tap = tiles_c0 + tiles_c1;
   const int Hup = p.up ? 2 * p.Hin : p.Hin, Wup = p.up ? 2 * p.Win : p.Win;
+  const char* const zero = p.zero + sc * 16;
 
-  const char* aptr[4];
-  int astep[4];
-  int seg_tap = -1, seg_src = -1;
-
-  auto set_segment = [&](int tap, int src) {
-    seg_tap = tap; seg_src = src;
+  // Prefetch cursor: K-tiles are visited segment by segment (tap-major, then source tensor); inside
+  // a segment every row pointer just advances by one 128-byte tile row, so the steady-state cost of
+  // issuing a tile is one 64-bit add per DMA.  Row pointers are rebuilt only at segment changes.
+  const char* acur[AP];
+  int astep[AP];
+  int pf_tap, pf_src, pf_left;      // current segment of the prefetcher and tiles left in it
+  auto set_segment = [&](int tap, int src, int cseg) {
+    pf_tap = tap; pf_src = src;
+    pf_left = (src ? tiles_c1 : tiles_c0) - cseg;
     const char* base = src ? p.a1 : p.a0;
     const int cs = src ? p.c1 : p.c0;
-    const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap % 3 - 1 : 0;
+    const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AP; ++i) {
       bool ok = a_ok[i];
       size_t pix;
       if (pointwise) {
@@ -188,25 +208,38 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(GemmParams p) {
         if (p.up) { iy >>= 1; ix >>= 1; }
         pix = ((size_t)a_b[i] * p.Hin + iy) * p.Win + ix;
       }
-      aptr[i] = ok ? base + pix * cs * sizeof(T) + sc * 16 : (const char*)g_zero_page + sc * 16;
+      if (p.dbg & 1) ok = false;
+      acur[i] = ok ? base + (pix * cs + (size_t)cseg * BK) * sizeof(T) + sc * 16 : zero;
       astep[i] = ok ? 128 : 0;
     }
   };
-
-  auto stage = [&](int kt, int buf) {
-    const int tap = kt / tiles_tap, rem = kt - tap * tiles_tap;
+  {
+    const int tap = kt_begin / tiles_tap, rem = kt_begin - tap * tiles_tap;
     const int src = rem >= tiles_c0 ? 1 : 0;
-    const int cseg = src ? rem - tiles_c0 : rem;
-    if (tap != seg_tap || src != seg_src) set_segment(tap, src);
-    char* abuf = smem + buf * 2 * TILE_BYTES;
-    char* wbuf = abuf + TILE_BYTES;
+    set_segment(tap, src, src ? rem - tiles_c0 : rem);
+  }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(aptr[i] + (size_t)cseg * astep[i], abuf + (wid * 4 + i) * 1024);
+  for (int i = 0; i < WP; ++i) wptr[i] += (size_t)kt_begin * wstep[i];
+
+  // issue the DMA of the cursor's tile into stage `buf`, then advance the cursor
+  auto prefetch = [&](int buf) {
+    if (!(p.dbg & 4)) {
+      char* abuf = smem + buf * S::STAGE_BYTES;
+      char* wbuf = abuf + S::A_BYTES;
+#pragma unroll
+      for (int i = 0; i < AP; ++i) glds16(acur[i], abuf + (wid * AP + i) * 1024);
+#pragma unroll
+      for (int i = 0; i < WP; ++i) glds16(wptr[i], wbuf + (wid * WP + i) * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(wptr[i] + (size_t)kt * wstep[i], wbuf + (wid * 4 + i) * 1024);
+    for (int i = 0; i < AP; ++i) acur[i] += astep[i];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) wptr[i] += wstep[i];
+    if (--pf_left == 0) {
+      int tap = pf_tap, src = pf_src;
+      if (src == 0 && tiles_c1 > 0) src = 1;
+      else { src = 0; ++tap; }
+      if (tap < p.taps) set_segment(tap, src, 0);
     }
   };
 
@@ -218,35 +251,46 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(GemmParams p) {
 
   // fragment read offsets (bytes) inside a tile: row*128 + ((chunk ^ (row&7)) * 16)
   const int frow = lane & 15, fq = lane >> 4;
-  int w_off[4], a_off[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    w_off[i] = (wn * 64 + i * 16 + frow) * 128;
-    a_off[i] = (wm * 64 + i * 16 + frow) * 128;
-  }
   const int sw = frow & 7;      // (row & 7) for every fragment row of this lane (16 | row offsets)
+  const int coff0 = (fq ^ sw) * 16, coff1 = ((4 + fq) ^ sw) * 16;
+  const int w_base = (wn * 64 + frow) * 128 + S::A_BYTES, a_base = (wm * 64 + frow) * 128;
 
-  if (kt_begin < kt_end) stage(kt_begin, 0);
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < kt_end) stage(kt + 1, buf ^ 1);
-    const char* abuf = smem + buf * 2 * TILE_BYTES;
-    const char* wbuf = abuf + TILE_BYTES;
+  // ---- main loop: NSTAGE-deep ring.  At the top of iteration `it` the wave waits until its own DMA
+  // of that tile has landed (leaving the younger tiles' DMAs in flight: counted vmcnt), the barrier
+  // makes every wave's part visible and proves that everyone has finished reading the stage of the
+  // previous tile, which is then refilled with tile it+NSTAGE-1.  One barrier per K-tile.  Inside an
+  // iteration the first half's fragments are read before the prefetch is issued and the second
+  // half's before the first half's MFMAs, so LDS latency hides behind address work and MFMAs.
+  const int nk = kt_end - kt_begin;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int coff = ((ks * 4 + fq) ^ sw) * 16;
-      frag_t wf[4], af[4];
+  for (int i = 0; i < NSTAGE - 1; ++i)
+    if (i < nk) prefetch(i);
+  for (int it = 0; it < nk; ++it) {
+    // younger tiles already issued and allowed to stay in flight: min(nk-1-it, NSTAGE-2)
+    const int younger = min(nk - 1 - it, NSTAGE - 2);
+    if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::GL) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * S::GL) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* sbuf = smem + (it % NSTAGE) * S::STAGE_BYTES;
+    frag_t wf0[4], af0[4], wf1[4], af1[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const frag_t*>(wbuf + w_off[i] + coff);
+    for (int i = 0; i < 4; ++i) wf0[i] = *reinterpret_cast<const frag_t*>(sbuf + w_base + i * 2048 + coff0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const frag_t*>(abuf + a_off[j] + coff);
+    for (int j = 0; j < 4; ++j) af0[j] = *reinterpret_cast<const frag_t*>(sbuf + a_base + j * 2048 + coff0);
+    if (it + NSTAGE - 1 < nk) prefetch((it + NSTAGE - 1) % NSTAGE);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) wf1[i] = *reinterpret_cast<const frag_t*>(sbuf + w_base + i * 2048 + coff1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mma(wf[i], af[j], acc[i][j]);
-    }
+    for (int j = 0; j < 4; ++j) af1[j] = *reinterpret_cast<const frag_t*>(sbuf + a_base + j * 2048 + coff1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mma(wf0[i], af0[j], acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mma(wf1[i], af1[j], acc[i][j]);
   }
 
   // ---- epilogue -----------------------------------------------------------------------------
@@ -322,20 +366,51 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
 }  // namespace
 
 // Raise the dynamic-LDS limit of every instantiation once (must not first happen under stream capture).
+namespace {
+template <typename T, typename S>
+int set_lds_limit() {
+  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_kernel<T, S>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS_BYTES));
+  return SDMI_OK;
+}
+template <typename S>
+int set_lds_limit_all() {
+  SDMI_TRY((set_lds_limit<float, S>()));
+  SDMI_TRY((set_lds_limit<half_t, S>()));
+  SDMI_TRY((set_lds_limit<bf16_t, S>()));
+  return SDMI_OK;
+}
+}  // namespace
+
+static char* g_zero_page = nullptr;     // device buffer of zeros, allocated once per process
+
 int conv_gemm_init() {
   static bool done = false;
   if (done) return SDMI_OK;
-  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_kernel<float>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_kernel<half_t>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_kernel<bf16_t>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  if (!g_zero_page) {
+    SDMI_CHECK_HIP(hipMalloc((void**)&g_zero_page, 4096));
+    SDMI_CHECK_HIP(hipMemset(g_zero_page, 0, 4096));
+  }
+  SDMI_TRY(set_lds_limit_all<ShapeSmall>());
+  SDMI_TRY(set_lds_limit_all<ShapeLarge>());
   done = true;
   return SDMI_OK;
 }
 
 namespace {
+
+// 256x128 blocks run one per CU: use them only when they still give every CU work; smaller problems
+// keep 128x128 blocks (two per CU) and split K.  SDMI_GEMM_SHAPE=1/2 forces small/large (experiments).
+bool use_large_shape(int M, int N) {
+  static const int forced = [] {
+    const char* e = getenv("SDMI_GEMM_SHAPE");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 1) return false;
+  if (forced == 2) return true;
+  const long tiles = (long)((M + ShapeLarge::BM - 1) / ShapeLarge::BM) * ((N + ShapeLarge::BN - 1) / ShapeLarge::BN);
+  return tiles >= 224;
+}
 
 template <typename T>
 int launch(const ConvGemmArgs& a, hipStream_t stream) {
@@ -371,13 +446,28 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   splits = (p.nkt + p.kt_per_split - 1) / p.kt_per_split;
   p.partial = splits > 1 ? a.partial : nullptr;
   SDMI_REQUIRE(splits == 1 || a.partial, "conv_gemm: split-K needs a partial buffer");
-  p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
-
   SDMI_TRY(conv_gemm_init());
-  ProfScope prof(PROF_CONV_GEMM, stream, 2.0 * p.M * (double)p.N * p.K,
-                 ((double)p.M * p.K / (p.taps == 9 ? 9 : 1) + (double)p.N * p.K + (double)p.M * p.N) * sizeof(T));
-  dim3 grid(p.tiles_m * p.tiles_n, splits);
-  hipLaunchKernelGGL(conv_gemm_kernel<T>, grid, dim3(NTHREADS), LDS_BYTES, stream, p);
+  {
+    static const int dbg = [] { const char* e = getenv("SDMI_GEMM_DEBUG_ZERO"); return e ? atoi(e) : 0; }();
+    p.dbg = dbg;
+  }
+  p.zero = g_zero_page;
+  const bool large = use_large_shape(p.M, p.N);
+  {
+    ProfScope prof(PROF_CONV_GEMM, stream, 2.0 * p.M * (double)p.N * p.K,
+                   ((double)p.M * p.K / (p.taps == 9 ? 9 : 1) + (double)p.N * p.K + (double)p.M * p.N) * sizeof(T));
+    if (large) {
+      typedef ShapeLarge S;
+      p.tiles_m = (p.M + S::BM - 1) / S::BM; p.tiles_n = (p.N + S::BN - 1) / S::BN;
+      hipLaunchKernelGGL((conv_gemm_kernel<T, S>), dim3(p.tiles_m * p.tiles_n, splits), dim3(S::NTHREADS),
+                         S::LDS_BYTES, stream, p);
+    } else {
+      typedef ShapeSmall S;
+      p.tiles_m = (p.M + S::BM - 1) / S::BM; p.tiles_n = (p.N + S::BN - 1) / S::BN;
+      hipLaunchKernelGGL((conv_gemm_kernel<T, S>), dim3(p.tiles_m * p.tiles_n, splits), dim3(S::NTHREADS),
+                         S::LDS_BYTES, stream, p);
+    }
+  }
   SDMI_CHECK_HIP(hipGetLastError());
   if (splits > 1) {
     const size_t total = (size_t)p.M * (p.N / 4);
@@ -398,7 +488,8 @@ int conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
 
 int conv_gemm_pick_splits(int M, int N, int K, int dtype) {
   const int BK = dtype == SDMI_F32 ? 32 : 64;
-  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  if (use_large_shape(M, N)) return 1;
+  const int tiles = ((M + ShapeSmall::BM - 1) / ShapeSmall::BM) * ((N + ShapeSmall::BN - 1) / ShapeSmall::BN);
   const int nkt = K / BK;
   if (tiles >= 192) return 1;
   int s = (384 + tiles - 1) / tiles;

@@ -96,6 +96,9 @@ def run_attn(B, dt=torch.float16):
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["gemm", "gn", "attn"]
+    if "gemm16" in what:
+        run_gemm(16)
+        sys.exit(0)
     for B in (16, 2):
         if "gemm" in what: run_gemm(B)
         if "gn" in what: run_gn(B)

@@ -158,6 +158,9 @@ int sdmi_conv2d(const void* a0, int c0, const void* a1, int c1, const void* w, c
                 const float* rowadd, const void* resid, int ldr, void* out, int ldo, int batch, int hin,
                 int win, int taps, int stride, int up, int n_out, int geglu, int splits, void* partial,
                 int dtype, void* stream);
+/* Split count the UNet executor uses for an (m x k) * (k x n) problem of this dtype (1 = no split);
+ * callers that want the executor's schedule size `partial` from it.  No counterpart in the reference. */
+int sdmi_conv2d_splits(int m, int n, int k, int dtype);
 /* softmax(q k^T * scale) v per (batch, head)  (CrossAttention :2784-2796); impl 0 auto, 1 scalar */
 int sdmi_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
                    int batch, int heads, int nq, int nk, int d, float scale, int dtype, int impl, void* stream);

@@ -67,6 +67,7 @@ SIGNATURES = {
     "sdmi_conv2d": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                             c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                             c_void_p, c_int, c_void_p]),
+    "sdmi_conv2d_splits": (c_int, [c_int, c_int, c_int, c_int]),
     "sdmi_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "sdmi_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),

@@ -141,6 +141,8 @@ int sdmi_conv2d(const void* a0, int c0, const void* a1, int c1, const void* w, c
   return conv_gemm(a, (hipStream_t)stream);
 }
 
+int sdmi_conv2d_splits(int m, int n, int k, int dtype) { return conv_gemm_pick_splits(m, n, k, dtype); }
+
 int sdmi_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
                    int batch, int heads, int nq, int nk, int d, float scale, int dtype, int impl, void* stream) {
   AttentionArgs a;

@@ -41,7 +41,6 @@ template <int WM_, int WN_, int NSTAGE_> struct Shape {
   static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must divide evenly over the waves");
 };
 typedef Shape<2, 2, 2> ShapeSmall;      // 128x128, 4 waves, 64 KiB: two blocks per CU (small-M layers)
-typedef Shape<4, 2, 3> ShapeLarge;      // 256x128, 8 waves, 144 KiB: one block per CU, two tiles in flight
 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -124,6 +123,51 @@ __device__ __forceinline__ void epilogue_store_geglu(const GemmParams& p, int m,
   typedef T Tx4 __attribute__((ext_vector_type(4)));
   Tx4 ov = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
   *reinterpret_cast<Tx4*>(o) = ov;
+}
+
+// Epilogue of one wave: acc[i][j] holds columns n_wave + 16 i + 4 fq .. +3 of row m_lane + 16 j.
+template <typename T, int NI, int MJ>
+__device__ __forceinline__ void store_wave_tile(const GemmParams& p, f32x4 (&acc)[NI][MJ], int m_lane, int n_wave,
+                                                int fq) {
+  const int nbase = n_wave + fq * 4;
+  if (p.partial) {
+    float* slab = p.partial + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+      const int m = m_lane + j * 16;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int n = nbase + i * 16;
+        if (n < p.N) *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
+  if (p.geglu) {
+    const int obase = n_wave / 2 + fq * 4;
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+      const int m = m_lane + j * 16;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < NI; i += 2) {
+        const int n = nbase + i * 16;
+        if (n < p.N) epilogue_store_geglu<T>(p, m, n, n + 16, obase + (i / 2) * 16, acc[i][j], acc[i + 1][j]);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    const int m = m_lane + j * 16;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = nbase + i * 16;
+      if (n < p.N) epilogue_store<T>(p, m, n, acc[i][j]);
+    }
+  }
 }
 
 template <typename T, typename S>
@@ -294,46 +338,227 @@ __global__ __launch_bounds__(S::NTHREADS) void conv_gemm_kernel(GemmParams p) {
   }
 
   // ---- epilogue -----------------------------------------------------------------------------
-  const int nbase = n0 + wn * 64 + fq * 4;
-  const int mbase = m0 + wm * 64 + frow;
-  if (p.partial) {
-    float* slab = p.partial + (size_t)blockIdx.y * p.M * p.N;
+  store_wave_tile<T, 4, 4>(p, acc, m0 + wm * 64 + frow, n0 + wn * 64, fq);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Large-tile kernel: 256(m) x 64*NH(n) per 512-thread workgroup, one workgroup per CU.
+//
+// A 128x128 tile moves 32 KiB of operands L2 -> LDS per 2.1 MFLOP, which is what bounds the kernel
+// above; a 256x320 tile moves 72 KiB per 10.5 MFLOP, less than half of that per flop.  With a single
+// workgroup on the CU the overlap of LDS traffic and MFMAs has to be built by hand: the 8 waves form
+// two groups of four (one wave of each group per SIMD) that run the same program one segment
+// apart.  A K-tile (64 deep) is four phases per wave; a phase is a read segment (ds_read of the
+// phase's fragments + a share of the next tile's LDS-DMA, retired with lgkmcnt(0)), a barrier, an
+// MFMA segment (4 x NH MFMAs), a barrier.  Group 1 enters the loop one barrier late, so in every
+// segment one group feeds the matrix cores while the other one reads.
+//
+// Wave (wr = wid & 3, grp = wid >> 2) owns rows wr*64..+63 and columns grp*32*NH.. (2 NH fragments); phase
+// (ks, h) multiplies k-step ks of the tile into the wave's column half h (NH fragments).
+//
+// Hazards.  Stage s of K-tile t is read in t's eight segments; the last reads (group 1, phase 3)
+// retire before the barrier that opens group 0's first segment of tile t+1, and the DMA of tile
+// t+2 into that stage is issued no earlier than that segment.  Every wave waits for its own DMA of
+// tile t+1 (vmcnt(0)) before the last barrier that precedes group 0's first read of it.
+template <int NH_> struct PPShape {
+  static constexpr int NH = NH_;
+  static constexpr int BM = 256, BN = 64 * NH, NTHREADS = 512;
+  static constexpr int AP = 4, WP = BN / 64;                        // 1-KiB DMA pieces per wave and tile
+  static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
+  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+  static_assert(BN % 64 == 0, "weight pieces must divide evenly over 8 waves");
+};
+
+template <typename T, int NH>
+__global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
+  typedef PPShape<NH> S;
+  static_assert(sizeof(T) == 2, "16-bit operands only");
+  constexpr int BK = 64, AP = S::AP, WP = S::WP;
+  typedef typename Frag<T>::type frag_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2, wr = wid & 3;
+
+  int id;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int tile_n = id % p.tiles_n, tile_m = id / p.tiles_n;
+  const int m0 = tile_m * S::BM, n0 = tile_n * S::BN;
+  const int kt_begin = blockIdx.y * p.kt_per_split;
+  const int nk = min(p.nkt, kt_begin + p.kt_per_split) - kt_begin;
+
+  // ---- loader state ----------------------------------------------------------------------------
+  const int lrow = lane >> 3;
+  const int sc = (lane & 7) ^ lrow;
+  const int hw = p.Ho * p.Wo;
+  const bool pointwise = (p.taps == 1 && p.stride == 1 && !p.up);
+  int a_b[AP], a_oy[AP], a_ox[AP];
+  bool a_ok[AP];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = mbase + j * 16;
-      if (m >= p.M) continue;
+  for (int i = 0; i < AP; ++i) {
+    const int m = m0 + (wid * AP + i) * 8 + lrow;
+    a_ok[i] = m < p.M;
+    const int mm = a_ok[i] ? m : 0;
+    if (pointwise) {
+      a_b[i] = 0; a_oy[i] = 0; a_ox[i] = mm;
+    } else {
+      const int b = mm / hw, rem = mm - b * hw;
+      a_b[i] = b; a_oy[i] = rem / p.Wo; a_ox[i] = rem - (rem / p.Wo) * p.Wo;
+    }
+  }
+  // weight rows: the launcher guarantees N % BN == 0, so every row exists
+  const char* wptr[WP];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int n = nbase + i * 16;
-        if (n < p.N) *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + n) = acc[i][j];
+  for (int i = 0; i < WP; ++i) {
+    const int n = n0 + (wid * WP + i) * 8 + lrow;
+    wptr[i] = p.w + ((size_t)n * p.K + (size_t)kt_begin * BK) * sizeof(T) + sc * 16;
+  }
+  const int tiles_c0 = p.c0 / BK, tiles_c1 = p.c1 / BK, tiles_tap = tiles_c0 + tiles_c1;
+  const int Hup = p.up ? 2 * p.Hin : p.Hin, Wup = p.up ? 2 * p.Win : p.Win;
+  const char* const zero = p.zero + sc * 16;
+
+  const char* acur[AP];
+  int astep[AP];
+  int pf_tap, pf_src, pf_left;
+  auto set_segment = [&](int tap, int src, int cseg) {
+    pf_tap = tap; pf_src = src;
+    pf_left = (src ? tiles_c1 : tiles_c0) - cseg;
+    const char* base = src ? p.a1 : p.a0;
+    const int cs = src ? p.c1 : p.c0;
+    const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      bool ok = a_ok[i];
+      size_t pix;
+      if (pointwise) {
+        pix = (size_t)a_ox[i];
+      } else {
+        int iy = a_oy[i] * p.stride + dy, ix = a_ox[i] * p.stride + dx;
+        ok = ok && iy >= 0 && iy < Hup && ix >= 0 && ix < Wup;
+        if (p.up) { iy >>= 1; ix >>= 1; }
+        pix = ((size_t)a_b[i] * p.Hin + iy) * p.Win + ix;
       }
+      acur[i] = ok ? base + (pix * cs + (size_t)cseg * BK) * sizeof(T) + sc * 16 : zero;
+      astep[i] = ok ? 128 : 0;
     }
-    return;
+  };
+  {
+    const int tap = kt_begin / tiles_tap, rem = kt_begin - tap * tiles_tap;
+    const int src = rem >= tiles_c0 ? 1 : 0;
+    set_segment(tap, src, src ? rem - tiles_c0 : rem);
   }
-  if (p.geglu) {
-    const int obase = (n0 + wn * 64) / 2 + fq * 4;
+  auto prefetch_a = [&](int buf) {
+    char* abuf = smem + buf * S::STAGE_BYTES;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = mbase + j * 16;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int i = 0; i < 4; i += 2) {
-        const int n = nbase + i * 16;
-        if (n < p.N) epilogue_store_geglu<T>(p, m, n, n + 16, obase + (i / 2) * 16, acc[i][j], acc[i + 1][j]);
-      }
+    for (int i = 0; i < AP; ++i) {
+      glds16(acur[i], abuf + (wid * AP + i) * 1024);
+      acur[i] += astep[i];
     }
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = mbase + j * 16;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = nbase + i * 16;
-      if (n < p.N) epilogue_store<T>(p, m, n, acc[i][j]);
+    if (--pf_left == 0) {
+      int tap = pf_tap, src = pf_src;
+      if (src == 0 && tiles_c1 > 0) src = 1;
+      else { src = 0; ++tap; }
+      if (tap < p.taps) set_segment(tap, src, 0);
     }
+  };
+  auto prefetch_w = [&](int buf) {
+    char* wbuf = smem + buf * S::STAGE_BYTES + S::A_BYTES;
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      glds16(wptr[i], wbuf + (wid * WP + i) * 1024);
+      wptr[i] += 128;
+    }
+  };
+
+  f32x4 acc[2 * NH][4];
+#pragma unroll
+  for (int i = 0; i < 2 * NH; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int sw = frow & 7;
+  const int coff0 = (fq ^ sw) * 16, coff1 = ((4 + fq) ^ sw) * 16;
+  const int a_base = (wr * 64 + frow) * 128;
+  const int w_base = S::A_BYTES + (grp * (S::BN / 2) + frow) * 128;
+
+  frag_t af[4], wf[NH];
+
+#define PP_READ_A(SB, COFF)                                                                     \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
+      af[j] = *reinterpret_cast<const frag_t*>((SB) + a_base + j * 2048 + (COFF));
+#define PP_READ_W(SB, H, COFF)                                                                  \
+  _Pragma("unroll") for (int i = 0; i < NH; ++i)                                                 \
+      wf[i] = *reinterpret_cast<const frag_t*>((SB) + w_base + ((H) * NH + i) * 2048 + (COFF));
+// end of a read segment: fragments in registers, then hand the matrix cores over
+#define PP_READ_DONE()                                                                          \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+  __builtin_amdgcn_sched_barrier(0);                                                            \
+  __builtin_amdgcn_s_barrier();                                                                 \
+  __builtin_amdgcn_sched_barrier(0);
+#define PP_MFMA(H)                                                                              \
+  __builtin_amdgcn_s_setprio(1);                                                                \
+  _Pragma("unroll") for (int i = 0; i < NH; ++i)                                                 \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
+          acc[(H) * NH + i][j] = mma(wf[i], af[j], acc[(H) * NH + i][j]);                       \
+  __builtin_amdgcn_s_setprio(0);
+#define PP_MFMA_DONE()                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                            \
+  __builtin_amdgcn_s_barrier();                                                                 \
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- prologue: tile 0 into stage 0, visible to everyone; then stagger the groups ------------
+  prefetch_a(0);
+  prefetch_w(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* sb = smem + (kt & 1) * S::STAGE_BYTES;
+    const int nb = (kt + 1) & 1;
+    const bool more = kt + 1 < nk;
+    // phase 0: k-step 0, column half 0
+    PP_READ_A(sb, coff0)
+    PP_READ_W(sb, 0, coff0)
+    if (more) prefetch_a(nb);
+    PP_READ_DONE()
+    PP_MFMA(0)
+    PP_MFMA_DONE()
+    // phase 1: k-step 0, column half 1
+    PP_READ_W(sb, 1, coff0)
+    if (more) prefetch_w(nb);
+    PP_READ_DONE()
+    PP_MFMA(1)
+    PP_MFMA_DONE()
+    // phase 2: k-step 1, column half 0
+    PP_READ_A(sb, coff1)
+    PP_READ_W(sb, 0, coff1)
+    PP_READ_DONE()
+    PP_MFMA(0)
+    PP_MFMA_DONE()
+    // phase 3: k-step 1, column half 1; the next tile's DMA is retired before the barrier that
+    // precedes group 0's first read of it
+    PP_READ_W(sb, 1, coff1)
+    if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_READ_DONE()
+    PP_MFMA(1)
+    if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_MFMA_DONE()
   }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+#undef PP_READ_A
+#undef PP_READ_W
+#undef PP_READ_DONE
+#undef PP_MFMA
+#undef PP_MFMA_DONE
+
+  store_wave_tile<T, 2 * NH, 4>(p, acc, m0 + wr * 64 + frow, n0 + grp * (S::BN / 2), fq);
 }
 
 // split-K second pass: sum the fp32 slabs and run the same epilogue.  One thread per 4 columns.
@@ -367,17 +592,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
 
 // Raise the dynamic-LDS limit of every instantiation once (must not first happen under stream capture).
 namespace {
-template <typename T, typename S>
-int set_lds_limit() {
-  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_kernel<T, S>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS_BYTES));
-  return SDMI_OK;
-}
-template <typename S>
-int set_lds_limit_all() {
-  SDMI_TRY((set_lds_limit<float, S>()));
-  SDMI_TRY((set_lds_limit<half_t, S>()));
-  SDMI_TRY((set_lds_limit<bf16_t, S>()));
+template <typename T>
+int set_lds_limits() {
+  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_kernel<T, ShapeSmall>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, ShapeSmall::LDS_BYTES));
+  if constexpr (sizeof(T) == 2) {
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, 5>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PPShape<5>::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, 4>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PPShape<4>::LDS_BYTES));
+  }
   return SDMI_OK;
 }
 }  // namespace
@@ -391,25 +615,90 @@ int conv_gemm_init() {
     SDMI_CHECK_HIP(hipMalloc((void**)&g_zero_page, 4096));
     SDMI_CHECK_HIP(hipMemset(g_zero_page, 0, 4096));
   }
-  SDMI_TRY(set_lds_limit_all<ShapeSmall>());
-  SDMI_TRY(set_lds_limit_all<ShapeLarge>());
+  SDMI_TRY(set_lds_limits<float>());
+  SDMI_TRY(set_lds_limits<half_t>());
+  SDMI_TRY(set_lds_limits<bf16_t>());
   done = true;
   return SDMI_OK;
 }
 
 namespace {
 
-// 256x128 blocks run one per CU: use them only when they still give every CU work; smaller problems
-// keep 128x128 blocks (two per CU) and split K.  SDMI_GEMM_SHAPE=1/2 forces small/large (experiments).
-bool use_large_shape(int M, int N) {
-  static const int forced = [] {
-    const char* e = getenv("SDMI_GEMM_SHAPE");
-    return e ? atoi(e) : 0;
-  }();
-  if (forced == 1) return false;
-  if (forced == 2) return true;
-  const long tiles = (long)((M + ShapeLarge::BM - 1) / ShapeLarge::BM) * ((N + ShapeLarge::BN - 1) / ShapeLarge::BN);
-  return tiles >= 224;
+// ---- kernel / split selection --------------------------------------------------------------------
+// A plan is (block shape, number of K splits).  Each candidate is priced with a two-constant model:
+// the workgroups are dealt to the CUs in rounds (512 small blocks or 256 large ones per round), a
+// round takes (K-tiles per split) x (time of one K-tile of that shape), and split-K adds the slab
+// round trip through HBM plus a launch.  The K-tile times are measured on MI355X with full grids.
+enum { KIND_SMALL = 0, KIND_PP5 = 1, KIND_PP4 = 2 };
+struct Plan { int kind, splits; };
+
+// SDMI_GEMM_SHAPE (tests, experiments; read on every call): 1 = 128x128 tiles only, 2 = large tiles
+// wherever they are legal.
+int forced_kind() {
+  const char* e = getenv("SDMI_GEMM_SHAPE");
+  return e ? atoi(e) : 0;
+}
+
+constexpr double T_KT_SMALL_US = 1.40;    // 128x128x64 K-tile, two blocks per CU
+constexpr double T_KT_PP5_US = 2.10;      // 256x320x64 K-tile, one block per CU
+constexpr double T_KT_PP4_US = 1.75;      // 256x256x64
+
+double split_cost_us(int M, int N, int splits) {
+  if (splits <= 1) return 0.0;
+  return 3.0 + (double)(splits + 1) * M * N * 4.0 / 4.0e6;      // slab write + read at ~4 TB/s, + launch
+}
+
+int small_splits(int M, int N, int nkt) {
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  if (tiles >= 192) return 1;
+  int s = (384 + tiles - 1) / tiles;
+  int smax = nkt / 4;
+  if (smax < 1) smax = 1;
+  if (s > smax) s = smax;
+  if (s > 32) s = 32;
+  return s < 1 ? 1 : s;
+}
+
+Plan make_plan(int M, int N, int K, int dtype) {
+  const int BK = dtype == SDMI_F32 ? 32 : 64;
+  const int nkt = K / BK;
+  Plan best;
+  best.kind = KIND_SMALL;
+  best.splits = small_splits(M, N, nkt);
+  if (dtype == SDMI_F32 || forced_kind() == 1 || nkt < 2) return best;
+  double best_t;
+  {
+    const long blocks = (long)((M + 127) / 128) * ((N + 127) / 128) * best.splits;
+    const int per = (nkt + best.splits - 1) / best.splits;
+    best_t = (double)((blocks + 511) / 512) * (per + 1.5) * T_KT_SMALL_US + split_cost_us(M, N, best.splits);
+  }
+  bool found = false;
+  for (int kind = KIND_PP5; kind <= KIND_PP4; ++kind) {
+    const int bn = kind == KIND_PP5 ? 320 : 256;
+    if (N % bn != 0) continue;
+    const double tk = kind == KIND_PP5 ? T_KT_PP5_US : T_KT_PP4_US;
+    const long tiles = (long)((M + 255) / 256) * (N / bn);
+    for (int s = 1; s <= 16; ++s) {
+      if (s > 1 && nkt / s < 8) break;
+      const int per = (nkt + s - 1) / s;
+      const double t = (double)((tiles * s + 255) / 256) * (per + 3.0) * tk + split_cost_us(M, N, s);
+      if (t < best_t || (forced_kind() == 2 && !found)) {
+        best_t = t; best.kind = kind; best.splits = s; found = true;
+      }
+    }
+  }
+  return best;
+}
+
+// kernel for an explicit split count (callers size the slab with conv_gemm_pick_splits)
+int pick_kind(int M, int N, int K, int dtype) { return make_plan(M, N, K, dtype).kind; }
+
+template <typename T, int NH>
+void launch_pp(GemmParams& p, int splits, hipStream_t stream) {
+  typedef PPShape<NH> S;
+  p.tiles_m = (p.M + S::BM - 1) / S::BM; p.tiles_n = p.N / S::BN;
+  hipLaunchKernelGGL((conv_gemm_pp_kernel<T, NH>), dim3(p.tiles_m * p.tiles_n, splits), dim3(S::NTHREADS),
+                     S::LDS_BYTES, stream, p);
 }
 
 template <typename T>
@@ -452,16 +741,15 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
     p.dbg = dbg;
   }
   p.zero = g_zero_page;
-  const bool large = use_large_shape(p.M, p.N);
+  const int kind = pick_kind(p.M, p.N, p.K, a.dtype);
   {
     ProfScope prof(PROF_CONV_GEMM, stream, 2.0 * p.M * (double)p.N * p.K,
                    ((double)p.M * p.K / (p.taps == 9 ? 9 : 1) + (double)p.N * p.K + (double)p.M * p.N) * sizeof(T));
-    if (large) {
-      typedef ShapeLarge S;
-      p.tiles_m = (p.M + S::BM - 1) / S::BM; p.tiles_n = (p.N + S::BN - 1) / S::BN;
-      hipLaunchKernelGGL((conv_gemm_kernel<T, S>), dim3(p.tiles_m * p.tiles_n, splits), dim3(S::NTHREADS),
-                         S::LDS_BYTES, stream, p);
-    } else {
+    if constexpr (sizeof(T) == 2) {
+      if (kind == KIND_PP5) launch_pp<T, 5>(p, splits, stream);
+      else if (kind == KIND_PP4) launch_pp<T, 4>(p, splits, stream);
+    }
+    if (kind == KIND_SMALL || sizeof(T) != 2) {
       typedef ShapeSmall S;
       p.tiles_m = (p.M + S::BM - 1) / S::BM; p.tiles_n = (p.N + S::BN - 1) / S::BN;
       hipLaunchKernelGGL((conv_gemm_kernel<T, S>), dim3(p.tiles_m * p.tiles_n, splits), dim3(S::NTHREADS),
@@ -486,16 +774,4 @@ int conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
   return SDMI_OK;
 }
 
-int conv_gemm_pick_splits(int M, int N, int K, int dtype) {
-  const int BK = dtype == SDMI_F32 ? 32 : 64;
-  if (use_large_shape(M, N)) return 1;
-  const int tiles = ((M + ShapeSmall::BM - 1) / ShapeSmall::BM) * ((N + ShapeSmall::BN - 1) / ShapeSmall::BN);
-  const int nkt = K / BK;
-  if (tiles >= 192) return 1;
-  int s = (384 + tiles - 1) / tiles;
-  int smax = nkt / 4;
-  if (smax < 1) smax = 1;
-  if (s > smax) s = smax;
-  if (s > 32) s = 32;
-  return s < 1 ? 1 : s;
-}
+int conv_gemm_pick_splits(int M, int N, int K, int dtype) { return make_plan(M, N, K, dtype).splits; }

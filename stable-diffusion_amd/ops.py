@@ -65,6 +65,8 @@ def conv2d(x, w_packed, bias=None, *, taps=9, stride=1, up=False, x1=None, rowad
     No = N // 2 if geglu else N
     out = torch.empty((B, Ho, Wo, No), dtype=x.dtype, device=x.device)
     partial = None
+    if splits is None:          # the executor's own choice for this shape
+        splits = _lib.lib().sdmi_conv2d_splits(B * Ho * Wo, N, taps * (C0 + C1), dtype_code(x.dtype))
     if splits > 1:
         partial = torch.empty((splits, B * Ho * Wo, N), dtype=torch.float32, device=x.device)
     check(_lib.lib().sdmi_conv2d(ptr(x), C0, ptr(x1), C1, ptr(w_packed), ptr(bias), ptr(rowadd), ptr(resid),

@@ -82,6 +82,67 @@ def test_conv2d(ops, dt, case):
     assert max_rel_err(nchw(y), ref) < TOL[dt], name
 
 
+# Large-tile (256 x 320 / 256 x 256, two wave groups) kernel: forced through the environment switch
+# because the planner only picks it for problems far larger than a CPU reference should chew on.
+PP_CASES = [
+    # name, B, H, W, C0, C1, Cout, taps, stride, up, splits
+    ("pp_c320", 1, 16, 16, 320, 0, 320, 9, 1, 0, 1),
+    ("pp_two_tiles_n", 2, 16, 16, 128, 0, 640, 9, 1, 0, 1),
+    ("pp_ragged_m", 3, 10, 10, 64, 0, 320, 9, 1, 0, 1),
+    ("pp_n256", 2, 12, 12, 128, 0, 512, 9, 1, 0, 1),
+    ("pp_concat", 2, 16, 16, 128, 64, 320, 9, 1, 0, 1),
+    ("pp_down", 2, 32, 32, 64, 0, 320, 9, 2, 0, 1),
+    ("pp_up", 2, 8, 8, 128, 0, 320, 9, 1, 1, 1),
+    ("pp_splitk", 2, 16, 16, 192, 0, 320, 9, 1, 0, 3),
+    ("pp_splitk_concat", 1, 16, 16, 128, 128, 256, 9, 1, 0, 4),
+    ("pp_pointwise", 1, 24, 24, 256, 0, 640, 1, 1, 0, 1),
+    ("pp_one_ktile_per_split", 1, 16, 16, 128, 0, 320, 1, 1, 0, 2),
+]
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("case", PP_CASES, ids=[c[0] for c in PP_CASES])
+def test_conv2d_large_tiles(ops, dt, case, monkeypatch):
+    monkeypatch.setenv("SDMI_GEMM_SHAPE", "2")
+    test_conv2d(ops, dt, case)
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_large_tiles_epilogues(ops, dt, monkeypatch):
+    """bias + time-embedding row add + residual and the GEGLU gate through the large-tile kernel."""
+    monkeypatch.setenv("SDMI_GEMM_SHAPE", "2")
+    B, H, W, C, Cout = 2, 16, 16, 128, 320
+    x = q(rnd("ppepi.x", (B, C, H, W)), dt)
+    w = q(rnd("ppepi.w", (Cout, C, 3, 3), -0.05, 0.05), dt)
+    b = rnd("ppepi.b", (Cout,))
+    emb = rnd("ppepi.emb", (B, Cout))
+    res = q(rnd("ppepi.res", (B, Cout, H, W)), dt)
+    ref = F.conv2d(x, w, b, padding=1) + emb[:, :, None, None] + res
+    wp = ops.pack_weight(w.cuda(), dt)
+    for splits in (1, 2):
+        y = ops.conv2d(nhwc(x, dt), wp, b.cuda(), taps=9, rowadd=emb.cuda(), resid=nhwc(res, dt), splits=splits)
+        assert max_rel_err(nchw(y), ref) < TOL[dt], splits
+    rows, d = 300, 320                                   # N = 8 d = 2560 = 8 x 320
+    x = q(rnd("ppgeglu.x", (rows, d)), dt)
+    w = q(rnd("ppgeglu.w", (8 * d, d), -0.1, 0.1), dt)
+    b = rnd("ppgeglu.b", (8 * d,))
+    a, g = F.linear(x, w, b).chunk(2, dim=-1)
+    ref = a * F.gelu(g)
+    wp, bp = ops.pack_geglu(w.cuda(), b.cuda(), dt)
+    for splits in (1, 2):
+        y = ops.linear(x.cuda().to(tdt(dt)), wp, bp, geglu=True, splits=splits)
+        assert max_rel_err(y.float().cpu(), ref) < TOL[dt]
+
+
+def test_conv2d_planned_splits(ops):
+    """splits=None asks the library for the executor's own split count."""
+    x = q(rnd("plan.x", (2, 256, 8, 8)), "fp16")
+    w = q(rnd("plan.w", (128, 256, 3, 3), -0.05, 0.05), "fp16")
+    ref = F.conv2d(x, w, None, padding=1)
+    y = ops.conv2d(nhwc(x, "fp16"), ops.pack_weight(w.cuda(), "fp16"), None, taps=9, splits=None)
+    assert max_rel_err(nchw(y), ref) < TOL["fp16"]
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_conv2d_epilogues(ops, dt):
     """bias + per-sample row add (time embedding) + residual, with and without split-K."""

@@ -53,13 +53,8 @@ def run_gemm(B, dt=torch.float16):
         Wo = ((2 * W if up else W) + 2 - 3) // stride + 1 if taps == 9 else W
         M = b * Ho * Wo
         K = taps * (C0 + C1)
-        import ctypes
         _lib = importlib.import_module("stable-diffusion_amd._lib")
-        # same split heuristic as the executor
-        splits = 1
-        tiles = ((M + 127) // 128) * ((Co + 127) // 128)
-        if tiles < 192:
-            splits = max(1, min((384 + tiles - 1) // tiles, (K // 64) // 4 or 1, 32))
+        splits = _lib.lib().sdmi_conv2d_splits(M, Co, K, _lib.dtype_code(dt))
         fn = lambda: ops.conv2d(x0, w, bias, taps=taps, stride=stride, up=bool(up), x1=x1, geglu=geglu, splits=splits)
         t = timeit(fn)
         fl = 2.0 * M * Co * K

@@ -182,6 +182,8 @@ int sdmi_convert_to_f32(const void* x, float* out, int64_t n, int dtype, void* s
 int sdmi_prof_enable(int on);
 int sdmi_prof_reset(void);
 int sdmi_prof_get(const char* kernel_class, double* ms_total, int64_t* launches, double* flops, double* bytes);
+/* Write one CSV line per profiled launch (class, shape label, microseconds, flops, bytes). */
+int sdmi_prof_dump(const char* path);
 
 #ifdef __cplusplus
 }

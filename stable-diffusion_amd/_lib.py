@@ -77,6 +77,7 @@ SIGNATURES = {
     "sdmi_convert_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "sdmi_prof_enable": (c_int, [c_int]),
     "sdmi_prof_reset": (c_int, []),
+    "sdmi_prof_dump": (c_int, [c_char_p]),
     "sdmi_prof_get": (c_int, [c_char_p, P(ctypes.c_double), P(c_int64), P(ctypes.c_double), P(ctypes.c_double)]),
 }
 

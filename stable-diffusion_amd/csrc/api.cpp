@@ -18,7 +18,7 @@ void sdmi_set_error(const char* fmt, ...) {
 #include <string.h>
 #include <vector>
 namespace {
-struct ProfEntry { hipEvent_t a, b; int cls; };
+struct ProfEntry { hipEvent_t a, b; int cls; double flops, bytes; char label[64]; };
 bool g_prof_on = false;
 std::vector<ProfEntry> g_prof_entries;
 std::vector<hipEvent_t> g_prof_pool;
@@ -33,9 +33,10 @@ hipEvent_t prof_event() {
 }
 }  // namespace
 
-void prof_begin(int cls, hipStream_t stream, double flops, double bytes) {
+void prof_begin(int cls, hipStream_t stream, double flops, double bytes, const char* label) {
   if (!g_prof_on) return;
-  ProfEntry e{prof_event(), prof_event(), cls};
+  ProfEntry e{prof_event(), prof_event(), cls, flops, bytes, {0}};
+  if (label) strncpy(e.label, label, sizeof(e.label) - 1);
   (void)hipEventRecord(e.a, stream);
   g_prof_entries.push_back(e);
   g_prof_flops[cls] += flops; g_prof_bytes[cls] += bytes; g_prof_launches[cls] += 1;
@@ -78,6 +79,21 @@ int sdmi_prof_get(const char* kernel_class, double* ms_total, int64_t* launches,
   if (launches) *launches = g_prof_launches[cls];
   if (flops) *flops = g_prof_flops[cls];
   if (bytes) *bytes = g_prof_bytes[cls];
+  return SDMI_OK;
+}
+
+int sdmi_prof_dump(const char* path) {
+  SDMI_REQUIRE(path, "prof_dump: null path");
+  SDMI_CHECK_HIP(hipDeviceSynchronize());
+  FILE* f = fopen(path, "w");
+  SDMI_REQUIRE(f, "prof_dump: cannot open '%s'", path);
+  fprintf(f, "class,label,us,flops,bytes\n");
+  for (const auto& e : g_prof_entries) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, e.a, e.b) != hipSuccess) t = -1.f;
+    fprintf(f, "%s,%s,%.3f,%.0f,%.0f\n", kProfNames[e.cls], e.label, t * 1e3, e.flops, e.bytes);
+  }
+  fclose(f);
   return SDMI_OK;
 }
 

@@ -20,6 +20,7 @@
 // stay unpadded in LDS (row stride = odd multiple of 16 bytes => conflict-free ds_read_b128) and the V
 // row stride is 64 or 192 (mod 256) bytes so the four key rows of a transpose read hit disjoint banks.
 #include "ops.h"
+#include <stdio.h>
 
 int attention_scalar(const AttentionArgs& a, hipStream_t stream);
 int attention_init();
@@ -276,7 +277,9 @@ int dispatch_flash(const AttentionArgs& a, hipStream_t stream, bool* handled) {
 int attention(const AttentionArgs& a, hipStream_t stream) {
   SDMI_REQUIRE(a.q && a.k && a.v && a.out, "attention: null pointer");
   SDMI_REQUIRE(a.B > 0 && a.heads > 0 && a.Nq > 0 && a.Nk > 0 && a.d > 0, "attention: empty problem");
-  ProfScope prof(PROF_ATTENTION, stream, 4.0 * a.B * a.heads * (double)a.Nq * a.Nk * a.d, 0.0);
+  char label[64];
+  snprintf(label, sizeof(label), "B%d h%d Nq%d Nk%d d%d", a.B, a.heads, a.Nq, a.Nk, a.d);
+  ProfScope prof(PROF_ATTENTION, stream, 4.0 * a.B * a.heads * (double)a.Nq * a.Nk * a.d, 0.0, label);
   if (a.impl != 1 && a.dtype != SDMI_F32) {
     SDMI_TRY(attention_init());
     SDMI_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 4 == 0,

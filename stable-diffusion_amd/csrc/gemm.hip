@@ -24,6 +24,7 @@
 // can be split over blockIdx.y; partial sums go to an fp32 slab and a second kernel reduces them
 // and applies the epilogue.
 #include "ops.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -55,6 +56,7 @@ struct GemmParams {
   float* partial;
   int tiles_m, tiles_n;
   const char* zero;   // 256 zero bytes (halo / out-of-range rows read these)
+  int wide_store;     // large-tile kernel: 16-bit output written through the LDS strips
   int dbg;   // timing experiments only: bit0 = activation loads hit the zero page, bit1 = weight loads
 };
 
@@ -167,6 +169,73 @@ __device__ __forceinline__ void store_wave_tile(const GemmParams& p, f32x4 (&acc
       const int n = nbase + i * 16;
       if (n < p.N) epilogue_store<T>(p, m, n, acc[i][j]);
     }
+  }
+}
+
+// Epilogue through LDS for 16-bit outputs: the MFMA layout gives a lane 4 channels (8 bytes) of one
+// pixel, so direct stores reach memory as 32-byte pieces.  Here the wave parks 16 rows at a time in a
+// private fp32 LDS strip and writes them back out as 16-byte pieces that run along the channel rows
+// (bias, time-embedding add and the GEGLU gate applied on the way in, the residual on the way out, all
+// in fp32, one rounding).  `strip` must hold 16 * (16 * NO + 4) floats, NO = output fragments per row.
+template <typename T, int NI, bool G>
+__device__ __forceinline__ void store_wave_tile_lds(const GemmParams& p, f32x4 (&acc)[NI][4], float* strip,
+                                                    int m_wave, int n_wave, int lane) {
+  constexpr int NO = G ? NI / 2 : NI;
+  constexpr int ROWF = NO * 16 + 4;
+  constexpr int CH = NO * 2;                    // 8-column chunks per row
+  constexpr int TOTAL = 16 * CH;
+  typedef T Tx8 __attribute__((ext_vector_type(8)));
+  const int frow = lane & 15, fq = lane >> 4;
+  const int n_out = G ? n_wave / 2 : n_wave;
+  const int hw = p.Ho * p.Wo;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    {
+      const int m = m_wave + j * 16 + frow;
+      const float* ra = nullptr;
+      if (!G && p.rowadd) ra = p.rowadd + (size_t)(min(m, p.M - 1) / hw) * p.ldra + n_wave + fq * 4;
+#pragma unroll
+      for (int io = 0; io < NO; ++io) {
+        f32x4 v;
+        if constexpr (G) {
+          f32x4 val = acc[2 * io][j], gate = acc[2 * io + 1][j];
+          if (p.bias) {
+            val += *reinterpret_cast<const f32x4*>(p.bias + n_wave + (2 * io) * 16 + fq * 4);
+            gate += *reinterpret_cast<const f32x4*>(p.bias + n_wave + (2 * io + 1) * 16 + fq * 4);
+          }
+          v = (f32x4){val.x * gelu_erf_f(gate.x), val.y * gelu_erf_f(gate.y), val.z * gelu_erf_f(gate.z),
+                      val.w * gelu_erf_f(gate.w)};
+        } else {
+          v = acc[io][j];
+          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n_wave + io * 16 + fq * 4);
+          if (ra) v += *reinterpret_cast<const f32x4*>(ra + io * 16);
+        }
+        *reinterpret_cast<f32x4*>(strip + frow * ROWF + io * 16 + fq * 4) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < (TOTAL + 63) / 64; ++k) {
+      const int c = lane + 64 * k;
+      const int row = c / CH, cc = c - row * CH;
+      const int m = m_wave + j * 16 + row;
+      if (c < TOTAL && m < p.M) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + row * ROWF + cc * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + row * ROWF + cc * 8 + 4);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (p.resid) {
+          const Tx8 r = *reinterpret_cast<const Tx8*>(reinterpret_cast<const T*>(p.resid) + (size_t)m * p.ldr +
+                                                      n_out + cc * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += to_f32(r[e]);
+        }
+        Tx8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(v[e]);
+        *reinterpret_cast<Tx8*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n_out + cc * 8) = o;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -558,6 +627,20 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
 #undef PP_MFMA
 #undef PP_MFMA_DONE
 
+  if (p.dbg & 8) {      // timing experiments: no epilogue (accumulators kept alive)
+#pragma unroll
+    for (int i = 0; i < 2 * NH; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
+  if (p.wide_store) {
+    // all stage reads and DMAs are retired behind the last barrier: the stages are free
+    float* strip = reinterpret_cast<float*>(smem + wid * (S::LDS_BYTES / 8));
+    if (p.geglu) store_wave_tile_lds<T, 2 * NH, true>(p, acc, strip, m0 + wr * 64, n0 + grp * (S::BN / 2), lane);
+    else store_wave_tile_lds<T, 2 * NH, false>(p, acc, strip, m0 + wr * 64, n0 + grp * (S::BN / 2), lane);
+    return;
+  }
   store_wave_tile<T, 2 * NH, 4>(p, acc, m0 + wr * 64 + frow, n0 + grp * (S::BN / 2), fq);
 }
 
@@ -742,9 +825,15 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   }
   p.zero = g_zero_page;
   const int kind = pick_kind(p.M, p.N, p.K, a.dtype);
+  p.wide_store = !p.partial && !p.out_f32 && sizeof(T) == 2 && a.ldo % 8 == 0 && (!a.resid || a.ldr % 8 == 0) &&
+                 ((uintptr_t)a.out % 16 == 0) && (!a.resid || (uintptr_t)a.resid % 16 == 0) && !(p.dbg & 16);
   {
+    char label[64];
+    snprintf(label, sizeof(label), "M%d N%d K%d t%d s%d u%d g%d x%d k%d", p.M, p.N, p.K, p.taps, p.stride, p.up,
+             p.geglu, splits, kind);
     ProfScope prof(PROF_CONV_GEMM, stream, 2.0 * p.M * (double)p.N * p.K,
-                   ((double)p.M * p.K / (p.taps == 9 ? 9 : 1) + (double)p.N * p.K + (double)p.M * p.N) * sizeof(T));
+                   ((double)p.M * p.K / (p.taps == 9 ? 9 : 1) + (double)p.N * p.K + (double)p.M * p.N) * sizeof(T),
+                   label);
     if constexpr (sizeof(T) == 2) {
       if (kind == KIND_PP5) launch_pp<T, 5>(p, splits, stream);
       else if (kind == KIND_PP4) launch_pp<T, 4>(p, splits, stream);

@@ -11,6 +11,7 @@
 // The input may be the channel-concatenation of two tensors (UNet skip connections); groups may
 // straddle the seam, which is why statistics are accumulated per channel first.
 #include "ops.h"
+#include <stdio.h>
 
 namespace {
 
@@ -238,7 +239,9 @@ int launch_gn(const GroupNormArgs& a, hipStream_t stream) {
   p.chunks = (p.HW + p.pix_per_chunk - 1) / p.pix_per_chunk;
   p.partial = a.scratch;
   p.stats = nullptr;
-  ProfScope prof(PROF_GROUPNORM, stream, 0.0, 2.0 * p.B * (double)p.HW * p.C * sizeof(T));
+  char label[64];
+  snprintf(label, sizeof(label), "B%d HW%d C%d", p.B, p.HW, p.C);
+  ProfScope prof(PROF_GROUPNORM, stream, 0.0, 2.0 * p.B * (double)p.HW * p.C * sizeof(T), label);
   hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(p.chunks, p.B), dim3(threads), 0, stream, p);
   hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(p.chunks, p.B), dim3(threads), 0, stream, p);
   SDMI_CHECK_HIP(hipGetLastError());

@@ -5,11 +5,13 @@
 
 // ---- optional per-kernel-class timing with HIP events (eager launches only; off by default) -------
 enum { PROF_CONV_GEMM = 0, PROF_ATTENTION = 1, PROF_GROUPNORM = 2, PROF_LAYERNORM = 3, PROF_OTHER = 4, PROF_NCLS = 5 };
-void prof_begin(int cls, hipStream_t stream, double flops, double bytes);
+void prof_begin(int cls, hipStream_t stream, double flops, double bytes, const char* label = nullptr);
 void prof_end(int cls, hipStream_t stream);
 struct ProfScope {
   int cls; hipStream_t s;
-  ProfScope(int c, hipStream_t st, double flops, double bytes) : cls(c), s(st) { prof_begin(c, st, flops, bytes); }
+  ProfScope(int c, hipStream_t st, double flops, double bytes, const char* label = nullptr) : cls(c), s(st) {
+    prof_begin(c, st, flops, bytes, label);
+  }
   ~ProfScope() { prof_end(cls, s); }
 };
 

@@ -67,10 +67,11 @@ template <int D> struct Geo {
   static constexpr int KBUF = KV_TILE * SK + 32;          // + zeroed tail for the last row's over-read
   static constexpr int VBUF = KV_TILE * SV;
   static constexpr int STAGE = KBUF + VBUF;
+  static constexpr bool ONES = (D % 32) != 0;             // a spare V column exists for the row sums
 };
 
 template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_flash_kernel(FlashParams p) {
+__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_flash_kernel(FlashParams p) {
   typedef Geo<D> G;
   typedef typename Mfma32<T>::v8 v8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -132,6 +133,16 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(FlashParams p) {
     const int buf = tid >> 1, part = tid & 1;
     *reinterpret_cast<u32x4*>(smem + buf * G::STAGE + KV_TILE * G::SK + part * 16) = (u32x4){0u, 0u, 0u, 0u};
   }
+  // Head sizes with spare columns in the last 32-wide output tile: V column D is set to 1 in both
+  // buffers (the staging never writes there), so output row D accumulates the softmax denominator on
+  // the matrix cores instead of 32 adds per tile and lane; the other spare columns are zeroed.
+  if constexpr (G::ONES) {
+    if (tid < 2 * KV_TILE) {
+      char* vrow = smem + (tid >> 6) * G::STAGE + G::KBUF + (tid & 63) * G::SV + D * 2;
+#pragma unroll
+      for (int e = 0; e < G::DT * 32 - D; ++e) reinterpret_cast<T*>(vrow)[e] = (T)(e == 0 ? 1.f : 0.f);
+    }
+  }
 
   f32x16 o[G::DT];
 #pragma unroll
@@ -176,27 +187,34 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(FlashParams p) {
     }
 
     // ---- online softmax (per lane = per query; partner lane ^ 32 holds the other keys) ----------
-    float mx = s0[0];
+    // The running maximum only moves when some query of the wave outgrows it by more than 2^8: P stays
+    // below 256 (exact range of both 16-bit formats, fp32 sums), and almost every tile skips the
+    // rescale of the output accumulators.
+    float mx = fmaxf(fmaxf(s0[0], s0[1]), s1[0]);
+    mx = fmaxf(fmaxf(mx, s1[1]), s0[2]);
 #pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s0[i]);
+    for (int i = 3; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s0[i]), s0[i + 1 < 16 ? i + 1 : i]);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s1[i]);
+    for (int i = 2; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s1[i]), s1[i + 1]);
     mx *= p.c;
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    l_run *= alpha;
+    if (__any(mx > m_run + 8.0f)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
 #pragma unroll
-    for (int dt = 0; dt < G::DT; ++dt)
+      for (int dt = 0; dt < G::DT; ++dt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+        for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+    }
+    const float m_new = m_run;
     v8 pf[4];        // P^T fragments: block 0 k-steps 0,1 then block 1 k-steps 0,1
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const float e0 = __builtin_amdgcn_exp2f(fmaf(s0[i], p.c, -m_new));
       const float e1 = __builtin_amdgcn_exp2f(fmaf(s1[i], p.c, -m_new));
-      l_run += e0 + e1;
+      if constexpr (!G::ONES) l_run += e0 + e1;
       pf[i >> 3][i & 7] = (T)e0;
       pf[2 + (i >> 3)][i & 7] = (T)e1;
     }
@@ -221,7 +239,13 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(FlashParams p) {
   }
 
   // ---- normalise and store: lane holds d = 32 dt + 8 (i>>2) + 4 h + (i&3) of its query --------------
-  l_run += __shfl_xor(l_run, 32, 64);
+  if constexpr (G::ONES) {
+    // output row D (the ones column) sits in the h = 0 half of the wave, register 4 * ((D % 32) / 8)
+    static_assert(D % 8 == 0 && (D % 32) % 8 == 0, "ones column must start an 8-row group");
+    l_run = __shfl(o[G::DT - 1][4 * ((D % 32) / 8)], r, 64);
+  } else {
+    l_run += __shfl_xor(l_run, 32, 64);
+  }
   const float inv = 1.0f / l_run;
   if (qi < p.Nq) {
     char* op = p.out + ((size_t)((size_t)b * p.Nq + qi) * p.ldo + (size_t)hd * D) * sizeof(T);

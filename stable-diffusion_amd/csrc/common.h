@@ -55,6 +55,24 @@ template <> struct VecOf<bf16_t> { typedef bf16_t type __attribute__((ext_vector
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU for 16-bit outputs: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the
+// output rounding of fp16 / bf16) -- one rcp, one exp2 and a degree-5 polynomial, no branches.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  const float erf_abs = fmaf(-poly * t, e, 1.0f);          // erf(|x| / sqrt 2)
+  const float half_x = 0.5f * x;
+  return fmaf(fabsf(half_x), erf_abs, half_x);               // 0.5 x (1 + sign(x) erf|.|)
+}
+template <typename T> __device__ __forceinline__ float gelu_for(float x) {
+  if constexpr (sizeof(T) == 2) return gelu_erf_fast(x);
+  else return gelu_erf_f(x);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

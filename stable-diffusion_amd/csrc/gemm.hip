@@ -119,8 +119,8 @@ __device__ __forceinline__ void epilogue_store_geglu(const GemmParams& p, int m,
     val += *reinterpret_cast<const f32x4*>(p.bias + n_val);
     gate += *reinterpret_cast<const f32x4*>(p.bias + n_gate);
   }
-  f32x4 v = {val.x * gelu_erf_f(gate.x), val.y * gelu_erf_f(gate.y), val.z * gelu_erf_f(gate.z),
-             val.w * gelu_erf_f(gate.w)};
+  f32x4 v = {val.x * gelu_for<T>(gate.x), val.y * gelu_for<T>(gate.y), val.z * gelu_for<T>(gate.z),
+             val.w * gelu_for<T>(gate.w)};
   T* o = reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n_out;
   typedef T Tx4 __attribute__((ext_vector_type(4)));
   Tx4 ov = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
@@ -203,8 +203,8 @@ __device__ __forceinline__ void store_wave_tile_lds(const GemmParams& p, f32x4 (
             val += *reinterpret_cast<const f32x4*>(p.bias + n_wave + (2 * io) * 16 + fq * 4);
             gate += *reinterpret_cast<const f32x4*>(p.bias + n_wave + (2 * io + 1) * 16 + fq * 4);
           }
-          v = (f32x4){val.x * gelu_erf_f(gate.x), val.y * gelu_erf_f(gate.y), val.z * gelu_erf_f(gate.z),
-                      val.w * gelu_erf_f(gate.w)};
+          v = (f32x4){val.x * gelu_for<T>(gate.x), val.y * gelu_for<T>(gate.y), val.z * gelu_for<T>(gate.z),
+                      val.w * gelu_for<T>(gate.w)};
         } else {
           v = acc[io][j];
           if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n_wave + io * 16 + fq * 4);

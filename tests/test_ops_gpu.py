@@ -249,6 +249,23 @@ def test_attention_forced_rescale(ops):
             assert max_rel_err(y.float().cpu(), ref) < TOL[dt] * 2
 
 
+@pytest.mark.parametrize("d", [40, 80, 160])
+def test_attention_ramping_scores(ops, d):
+    """Scores that keep growing along the key axis: the running maximum moves in many small steps
+    (below and above the rescale threshold), through both the ones-column and the VALU row-sum path."""
+    heads, B, N = 8, 1, 512
+    C = heads * d
+    qv = rnd(f"attramp{d}.q", (B, N, C), -1., 1.)
+    kv = rnd(f"attramp{d}.k", (B, N, C), -1., 1.) + qv * torch.linspace(0., 1.5, N)[None, :, None]
+    vv = rnd(f"attramp{d}.v", (B, N, C), -1., 1.)
+    for dt in ("fp16", "bf16"):
+        qq, kk, vq = q(qv, dt), q(kv, dt), q(vv, dt)
+        ref = _attn_ref(qq, kk, vq, heads)
+        dev = lambda t: t.cuda().to(tdt(dt))
+        y = ops.attention(dev(qq), dev(kk), dev(vq), heads)
+        assert max_rel_err(y.float().cpu(), ref) < TOL[dt] * 2
+
+
 def test_timestep_embedding_g1(ops):
     g = golden("g1_timestep_embedding")
     y = ops.timestep_embedding(g["t"].cuda(), 320).cpu()

@@ -172,68 +172,78 @@ __device__ __forceinline__ void store_wave_tile(const GemmParams& p, f32x4 (&acc
   }
 }
 
-// Epilogue through LDS for 16-bit outputs: the MFMA layout gives a lane 4 channels (8 bytes) of one
-// pixel, so direct stores reach memory as 32-byte pieces.  Here the wave parks 16 rows at a time in a
+// Epilogue through LDS: the MFMA layout gives a lane 4 channels of one pixel, so direct stores reach
+// memory as 8- or 16-byte pieces scattered over 16 rows.  Here the wave parks 16 rows at a time in a
 // private fp32 LDS strip and writes them back out as 16-byte pieces that run along the channel rows
-// (bias, time-embedding add and the GEGLU gate applied on the way in, the residual on the way out, all
-// in fp32, one rounding).  `strip` must hold 16 * (16 * NO + 4) floats, NO = output fragments per row.
-template <typename T, int NI, bool G>
+// (GEGLU gate applied on the way in, the residual on the way out, in fp32, one rounding).  OutT is
+// the stored type: T, or float for split-K slabs and fp32 outputs.  `strip` must hold
+// 16 * (16 * NO + 4) floats, NO = output fragments per row.
+template <typename T, typename OutT, int NI, bool G>
 __device__ __forceinline__ void store_wave_tile_lds(const GemmParams& p, f32x4 (&acc)[NI][4], float* strip,
-                                                    int m_wave, int n_wave, int lane) {
+                                                    OutT* out, int ldo, int m_wave, int n_wave, int lane) {
   constexpr int NO = G ? NI / 2 : NI;
   constexpr int ROWF = NO * 16 + 4;
-  constexpr int CH = NO * 2;                    // 8-column chunks per row
+  constexpr int EPC = 16 / (int)sizeof(OutT);   // elements per 16-byte piece
+  constexpr int CH = NO * 16 / EPC;             // pieces per row
   constexpr int TOTAL = 16 * CH;
-  typedef T Tx8 __attribute__((ext_vector_type(8)));
+  constexpr int KI = (TOTAL + 63) / 64;         // pieces per lane and 16-row strip
+  typedef T Tres __attribute__((ext_vector_type(EPC)));
+  typedef OutT Tout __attribute__((ext_vector_type(EPC)));
   const int frow = lane & 15, fq = lane >> 4;
   const int n_out = G ? n_wave / 2 : n_wave;
-  const int hw = p.Ho * p.Wo;
+  // Bias and time-embedding terms are already in the accumulators (the kernel starts from them).
+  // The residual loads are issued unconditionally on clamped addresses, a strip's worth at a time,
+  // ahead of the LDS round trip that hides their latency.
+  int c_row[KI], c_col[KI];
+#pragma unroll
+  for (int k = 0; k < KI; ++k) {
+    const int c = min(lane + 64 * k, TOTAL - 1);
+    c_row[k] = c / CH;
+    c_col[k] = (c - c_row[k] * CH) * EPC;
+  }
+  const bool has_resid = p.resid != nullptr;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    {
-      const int m = m_wave + j * 16 + frow;
-      const float* ra = nullptr;
-      if (!G && p.rowadd) ra = p.rowadd + (size_t)(min(m, p.M - 1) / hw) * p.ldra + n_wave + fq * 4;
+    Tres res[KI];
+    if (has_resid) {
 #pragma unroll
-      for (int io = 0; io < NO; ++io) {
-        f32x4 v;
-        if constexpr (G) {
-          f32x4 val = acc[2 * io][j], gate = acc[2 * io + 1][j];
-          if (p.bias) {
-            val += *reinterpret_cast<const f32x4*>(p.bias + n_wave + (2 * io) * 16 + fq * 4);
-            gate += *reinterpret_cast<const f32x4*>(p.bias + n_wave + (2 * io + 1) * 16 + fq * 4);
-          }
-          v = (f32x4){val.x * gelu_for<T>(gate.x), val.y * gelu_for<T>(gate.y), val.z * gelu_for<T>(gate.z),
-                      val.w * gelu_for<T>(gate.w)};
-        } else {
-          v = acc[io][j];
-          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n_wave + io * 16 + fq * 4);
-          if (ra) v += *reinterpret_cast<const f32x4*>(ra + io * 16);
-        }
-        *reinterpret_cast<f32x4*>(strip + frow * ROWF + io * 16 + fq * 4) = v;
+      for (int k = 0; k < KI; ++k) {
+        const int m = min(m_wave + j * 16 + c_row[k], p.M - 1);
+        res[k] = *reinterpret_cast<const Tres*>(reinterpret_cast<const T*>(p.resid) + (size_t)m * p.ldr + n_out +
+                                                c_col[k]);
       }
+    }
+#pragma unroll
+    for (int io = 0; io < NO; ++io) {
+      f32x4 v;
+      if constexpr (G) {
+        const f32x4 val = acc[2 * io][j], gate = acc[2 * io + 1][j];
+        v = (f32x4){val.x * gelu_for<T>(gate.x), val.y * gelu_for<T>(gate.y), val.z * gelu_for<T>(gate.z),
+                    val.w * gelu_for<T>(gate.w)};
+      } else {
+        v = acc[io][j];
+      }
+      *reinterpret_cast<f32x4*>(strip + frow * ROWF + io * 16 + fq * 4) = v;
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k = 0; k < (TOTAL + 63) / 64; ++k) {
-      const int c = lane + 64 * k;
-      const int row = c / CH, cc = c - row * CH;
-      const int m = m_wave + j * 16 + row;
-      if (c < TOTAL && m < p.M) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + row * ROWF + cc * 8);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + row * ROWF + cc * 8 + 4);
-        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        if (p.resid) {
-          const Tx8 r = *reinterpret_cast<const Tx8*>(reinterpret_cast<const T*>(p.resid) + (size_t)m * p.ldr +
-                                                      n_out + cc * 8);
+    for (int k = 0; k < KI; ++k) {
+      const int m = m_wave + j * 16 + c_row[k];
+      float v[EPC];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += to_f32(r[e]);
-        }
-        Tx8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(v[e]);
-        *reinterpret_cast<Tx8*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n_out + cc * 8) = o;
+      for (int e = 0; e < EPC; e += 4) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(strip + c_row[k] * ROWF + c_col[k] + e);
+        v[e] = q.x; v[e + 1] = q.y; v[e + 2] = q.z; v[e + 3] = q.w;
       }
+      if (has_resid) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] += to_f32(res[k][e]);
+      }
+      Tout o;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) o[e] = from_f32<OutT>(v[e]);
+      if (lane + 64 * k < TOTAL && m < p.M && (!(p.dbg & 32) || v[0] == 12345.678f))
+        *reinterpret_cast<Tout*>(out + (size_t)m * ldo + n_out + c_col[k]) = o;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -466,33 +476,31 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   const int sc = (lane & 7) ^ lrow;
   const int hw = p.Ho * p.Wo;
   const bool pointwise = (p.taps == 1 && p.stride == 1 && !p.up);
-  int a_b[AP], a_oy[AP], a_ox[AP];
-  bool a_ok[AP];
+  // per row: sample index (-1 = row beyond M) and the output pixel packed as (oy << 16 | ox); for
+  // pointwise problems the pixel is the row index itself
+  int a_b[AP], a_px[AP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
     const int m = m0 + (wid * AP + i) * 8 + lrow;
-    a_ok[i] = m < p.M;
-    const int mm = a_ok[i] ? m : 0;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
     if (pointwise) {
-      a_b[i] = 0; a_oy[i] = 0; a_ox[i] = mm;
+      a_b[i] = ok ? 0 : -1; a_px[i] = mm;
     } else {
       const int b = mm / hw, rem = mm - b * hw;
-      a_b[i] = b; a_oy[i] = rem / p.Wo; a_ox[i] = rem - (rem / p.Wo) * p.Wo;
+      const int oy = rem / p.Wo;
+      a_b[i] = ok ? b : -1; a_px[i] = (oy << 16) | (rem - oy * p.Wo);
     }
   }
-  // weight rows: the launcher guarantees N % BN == 0, so every row exists
-  const char* wptr[WP];
-#pragma unroll
-  for (int i = 0; i < WP; ++i) {
-    const int n = n0 + (wid * WP + i) * 8 + lrow;
-    wptr[i] = p.w + ((size_t)n * p.K + (size_t)kt_begin * BK) * sizeof(T) + sc * 16;
-  }
+  // weight rows: the launcher guarantees N % BN == 0, so every row exists.  One 32-bit byte offset per
+  // lane; the pieces of a tile differ by a wave-uniform stride (scalar base + vector offset loads).
+  unsigned wofs = (unsigned)(((size_t)(n0 + wid * WP * 8 + lrow) * p.K + (size_t)kt_begin * BK) * sizeof(T)) + sc * 16;
+  const size_t wpitch8 = (size_t)8 * p.K * sizeof(T);
   const int tiles_c0 = p.c0 / BK, tiles_c1 = p.c1 / BK, tiles_tap = tiles_c0 + tiles_c1;
   const int Hup = p.up ? 2 * p.Hin : p.Hin, Wup = p.up ? 2 * p.Win : p.Win;
   const char* const zero = p.zero + sc * 16;
 
-  const char* acur[AP];
-  int astep[AP];
+  const char* acur[AP];         // rows outside the image / beyond M sit on the zero page and do not advance
   int pf_tap, pf_src, pf_left;
   auto set_segment = [&](int tap, int src, int cseg) {
     pf_tap = tap; pf_src = src;
@@ -502,18 +510,17 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
     const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-      bool ok = a_ok[i];
+      bool ok = a_b[i] >= 0;
       size_t pix;
       if (pointwise) {
-        pix = (size_t)a_ox[i];
+        pix = (size_t)a_px[i];
       } else {
-        int iy = a_oy[i] * p.stride + dy, ix = a_ox[i] * p.stride + dx;
+        int iy = (a_px[i] >> 16) * p.stride + dy, ix = (a_px[i] & 0xffff) * p.stride + dx;
         ok = ok && iy >= 0 && iy < Hup && ix >= 0 && ix < Wup;
         if (p.up) { iy >>= 1; ix >>= 1; }
         pix = ((size_t)a_b[i] * p.Hin + iy) * p.Win + ix;
       }
       acur[i] = ok ? base + (pix * cs + (size_t)cseg * BK) * sizeof(T) + sc * 16 : zero;
-      astep[i] = ok ? 128 : 0;
     }
   };
   {
@@ -526,7 +533,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       glds16(acur[i], abuf + (wid * AP + i) * 1024);
-      acur[i] += astep[i];
+      acur[i] += acur[i] != zero ? 128 : 0;
     }
     if (--pf_left == 0) {
       int tap = pf_tap, src = pf_src;
@@ -538,19 +545,36 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   auto prefetch_w = [&](int buf) {
     char* wbuf = smem + buf * S::STAGE_BYTES + S::A_BYTES;
 #pragma unroll
-    for (int i = 0; i < WP; ++i) {
-      glds16(wptr[i], wbuf + (wid * WP + i) * 1024);
-      wptr[i] += 128;
-    }
+    for (int i = 0; i < WP; ++i) glds16(p.w + i * wpitch8 + wofs, wbuf + (wid * WP + i) * 1024);
+    wofs += 128;
   };
 
-  f32x4 acc[2 * NH][4];
-#pragma unroll
-  for (int i = 0; i < 2 * NH; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   const int frow = lane & 15, fq = lane >> 4;
+  // The accumulators start from the per-column bias and the per-(sample, column) time-embedding term
+  // (when this launch owns the epilogue): their loads overlap the first tile's DMA and the epilogue
+  // is left with the residual only.
+  f32x4 acc[2 * NH][4];
+  const bool own_epilogue = p.partial == nullptr;
+  {
+    const int ncol = n0 + grp * (S::BN / 2) + fq * 4;
+#pragma unroll
+    for (int i = 0; i < 2 * NH; ++i) {
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (own_epilogue && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + ncol + i * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = bv;
+    }
+    if (own_epilogue && p.rowadd) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = min(m0 + wr * 64 + j * 16 + frow, p.M - 1);
+        const float* ra = p.rowadd + (size_t)(m / hw) * p.ldra + ncol;
+#pragma unroll
+        for (int i = 0; i < 2 * NH; ++i) acc[i][j] += *reinterpret_cast<const f32x4*>(ra + i * 16);
+        __builtin_amdgcn_sched_barrier(0);        // one row group's loads in flight at a time (registers)
+      }
+    }
+  }
   const int sw = frow & 7;
   const int coff0 = (fq ^ sw) * 16, coff1 = ((4 + fq) ^ sw) * 16;
   const int a_base = (wr * 64 + frow) * 128;
@@ -634,14 +658,29 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
       for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
+  GemmParams pe = p;
+  if (own_epilogue) { pe.bias = nullptr; pe.rowadd = nullptr; }      // already in the accumulators
+  const int m_wave = m0 + wr * 64, n_wave = n0 + grp * (S::BN / 2);
   if (p.wide_store) {
     // all stage reads and DMAs are retired behind the last barrier: the stages are free
     float* strip = reinterpret_cast<float*>(smem + wid * (S::LDS_BYTES / 8));
-    if (p.geglu) store_wave_tile_lds<T, 2 * NH, true>(p, acc, strip, m0 + wr * 64, n0 + grp * (S::BN / 2), lane);
-    else store_wave_tile_lds<T, 2 * NH, false>(p, acc, strip, m0 + wr * 64, n0 + grp * (S::BN / 2), lane);
+    if (p.partial) {
+      pe.resid = nullptr;                                            // applied by the reduction pass
+      store_wave_tile_lds<T, float, 2 * NH, false>(pe, acc, strip, p.partial + (size_t)blockIdx.y * p.M * p.N, p.N,
+                                                   m_wave, n_wave, lane);
+    } else if (p.out_f32) {
+      store_wave_tile_lds<T, float, 2 * NH, false>(pe, acc, strip, reinterpret_cast<float*>(p.out), p.ldo, m_wave,
+                                                   n_wave, lane);
+    } else if (p.geglu) {
+      store_wave_tile_lds<T, T, 2 * NH, true>(pe, acc, strip, reinterpret_cast<T*>(p.out), p.ldo, m_wave, n_wave,
+                                              lane);
+    } else {
+      store_wave_tile_lds<T, T, 2 * NH, false>(pe, acc, strip, reinterpret_cast<T*>(p.out), p.ldo, m_wave, n_wave,
+                                               lane);
+    }
     return;
   }
-  store_wave_tile<T, 2 * NH, 4>(p, acc, m0 + wr * 64 + frow, n0 + grp * (S::BN / 2), fq);
+  store_wave_tile<T, 2 * NH, 4>(pe, acc, m_wave + frow, n_wave, fq);
 }
 
 // split-K second pass: sum the fp32 slabs and run the same epilogue.  One thread per 4 columns.
@@ -825,8 +864,9 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   }
   p.zero = g_zero_page;
   const int kind = pick_kind(p.M, p.N, p.K, a.dtype);
-  p.wide_store = !p.partial && !p.out_f32 && sizeof(T) == 2 && a.ldo % 8 == 0 && (!a.resid || a.ldr % 8 == 0) &&
-                 ((uintptr_t)a.out % 16 == 0) && (!a.resid || (uintptr_t)a.resid % 16 == 0) && !(p.dbg & 16);
+  p.wide_store = a.ldo % 8 == 0 && (!a.resid || a.ldr % 8 == 0) && ((uintptr_t)a.out % 16 == 0) &&
+                 (!a.resid || (uintptr_t)a.resid % 16 == 0) && (!p.partial || (uintptr_t)p.partial % 16 == 0) &&
+                 !(p.out_f32 && p.geglu) && !(p.dbg & 16);
   {
     char label[64];
     snprintf(label, sizeof(label), "M%d N%d K%d t%d s%d u%d g%d x%d k%d", p.M, p.N, p.K, p.taps, p.stride, p.up,

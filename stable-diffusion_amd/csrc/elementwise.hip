@@ -28,36 +28,60 @@ __global__ void timestep_embedding_kernel(const int64_t* t, float* out, int B, i
   if ((dim & 1) && k == 0) out[(size_t)b * dim + dim - 1] = 0.f;
 }
 
-// ---- tiny-M linear: one wave per output column, all rows at once ----------------------------------
+// ---- tiny-M linear -------------------------------------------------------------------------------
+// y[m][n] = act_out(sum_k act_in(x[m][k]) W[n][k] + bias[n]) for a handful of rows (time embedding MLP,
+// the per-block embedding projections).  The weight matrix is the only large operand and is read
+// exactly once: a workgroup parks its MB rows of x (activation applied) in LDS, every wave streams
+// NPW weight rows at a time with 16-byte loads (lane <-> k), multiplies them against all MB rows and
+// folds the lanes at the end.
+constexpr int SL_NPW = 4;          // weight rows per wave and pass
+constexpr int SL_PASSES = 2;       // passes per wave
+
 template <int MB>
 __global__ __launch_bounds__(256) void small_linear_kernel(const float* x, const float* W, const float* bias,
                                                            float* y, int M, int K, int N, int act_in, int act_out) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  extern __shared__ __attribute__((aligned(16))) float sl_x[];          // [MB][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mb = blockIdx.y * MB;
-  if (n >= N) return;
-  float acc[MB];
+  for (int i = tid; i < MB * K; i += 256) {
+    const int m = i / K;
+    float v = mb + m < M ? x[(size_t)(mb + m) * K + (i - m * K)] : 0.f;
+    if (act_in == 1) v = silu_f(v);
+    sl_x[i] = v;
+  }
+  __syncthreads();
+  for (int pass = 0; pass < SL_PASSES; ++pass) {
+    const int n0 = ((blockIdx.x * SL_PASSES + pass) * 4 + wave) * SL_NPW;
+    if (n0 >= N) return;
+    float acc[SL_NPW][MB];
 #pragma unroll
-  for (int m = 0; m < MB; ++m) acc[m] = 0.f;
-  for (int k = lane; k < K; k += 64) {
-    const float w = W[(size_t)n * K + k];
+    for (int j = 0; j < SL_NPW; ++j)
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      if (mb + m < M) {
-        float xv = x[(size_t)(mb + m) * K + k];
-        if (act_in == 1) xv = silu_f(xv);
-        acc[m] += xv * w;
+      for (int m = 0; m < MB; ++m) acc[j][m] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      float4 w[SL_NPW];
+#pragma unroll
+      for (int j = 0; j < SL_NPW; ++j)
+        w[j] = *reinterpret_cast<const float4*>(W + (size_t)min(n0 + j, N - 1) * K + k);
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const float4 xv = *reinterpret_cast<const float4*>(sl_x + m * K + k);
+#pragma unroll
+        for (int j = 0; j < SL_NPW; ++j)
+          acc[j][m] += xv.x * w[j].x + xv.y * w[j].y + xv.z * w[j].z + xv.w * w[j].w;
       }
     }
-  }
 #pragma unroll
-  for (int m = 0; m < MB; ++m) {
-    const float s = wave_sum(acc[m]);
-    if (lane == 0 && mb + m < M) {
-      float v = s + (bias ? bias[n] : 0.f);
-      if (act_out == 1) v = silu_f(v);
-      y[(size_t)(mb + m) * N + n] = v;
-    }
+    for (int j = 0; j < SL_NPW; ++j)
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const float sum = wave_sum(acc[j][m]);
+        if (lane == 0 && n0 + j < N && mb + m < M) {
+          float v = sum + (bias ? bias[n0 + j] : 0.f);
+          if (act_out == 1) v = silu_f(v);
+          y[(size_t)(mb + m) * N + n0 + j] = v;
+        }
+      }
   }
 }
 
@@ -68,15 +92,34 @@ struct InConvParams {
   int B, H, W, Cout;
 };
 
+// A thread owns 8 consecutive output channels of one pixel and a workgroup walks pixels with the
+// whole [9 Cin][Cout] fp32 weight block parked in LDS (46 KiB for 4 -> 320): the 36 input values of a
+// pixel are read once per thread (broadcast across the pixel's threads), every weight comes from LDS
+// as 2 x 16 bytes per 8 FMAs, and the store is 16 bytes per thread, 640 contiguous bytes per pixel.
+// Summation order per output: bias, then taps in order, sources in order, channels in order.
 template <typename T>
 __global__ __launch_bounds__(256) void in_conv_kernel(InConvParams p) {
-  const size_t total = (size_t)p.B * p.H * p.W * p.Cout;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * blockDim.x) {
-    const int co = (int)(idx % p.Cout);
-    const size_t pix = idx / p.Cout;
-    const int x = (int)(pix % p.W), y = (int)((pix / p.W) % p.H), b = (int)(pix / ((size_t)p.W * p.H));
-    float acc = p.bias[co];
+  extern __shared__ __attribute__((aligned(16))) float in_conv_w[];
+  const int tid = threadIdx.x;
+  const int nw = 9 * p.Cin * p.Cout;
+  for (int i = tid * 4; i < nw; i += 256 * 4)
+    *reinterpret_cast<float4*>(in_conv_w + i) = *reinterpret_cast<const float4*>(p.w + i);
+  __syncthreads();
+  const int tpp = p.Cout / 8;                 // threads per pixel
+  const int ppb = 256 / tpp;                  // pixels per workgroup pass
+  const int tp = tid % tpp, pl = tid / tpp;
+  if (pl >= ppb) return;
+  const int co = tp * 8;
+  float bias[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias[e] = p.bias[co + e];
+  const size_t npix = (size_t)p.B * p.H * p.W;
+  const size_t hw = (size_t)p.H * p.W;
+  for (size_t pix = (size_t)blockIdx.x * ppb + pl; pix < npix; pix += (size_t)gridDim.x * ppb) {
+    const int x = (int)(pix % p.W), y = (int)((pix / p.W) % p.H), b = (int)(pix / hw);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bias[e];
     for (int tap = 0; tap < 9; ++tap) {
       const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
       if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) continue;
@@ -85,12 +128,26 @@ __global__ __launch_bounds__(256) void in_conv_kernel(InConvParams p) {
       for (int s = 0; s < 3; ++s) {
         if (p.c[s] == 0) continue;
         const float* sp = p.src[s] + ((size_t)b * p.c[s] * p.H + iy) * p.W + ix;
-        for (int ci = 0; ci < p.c[s]; ++ci)
-          acc += sp[(size_t)ci * p.H * p.W] * p.w[((size_t)tap * p.Cin + cbase + ci) * p.Cout + co];
+        for (int ci = 0; ci < p.c[s]; ++ci) {
+          const float xv = sp[(size_t)ci * hw];
+          const float* wr = in_conv_w + (size_t)(tap * p.Cin + cbase + ci) * p.Cout + co;
+          const float4 w0 = *reinterpret_cast<const float4*>(wr), w1 = *reinterpret_cast<const float4*>(wr + 4);
+          acc[0] += xv * w0.x; acc[1] += xv * w0.y; acc[2] += xv * w0.z; acc[3] += xv * w0.w;
+          acc[4] += xv * w1.x; acc[5] += xv * w1.y; acc[6] += xv * w1.z; acc[7] += xv * w1.w;
+        }
         cbase += p.c[s];
       }
     }
-    ((T*)p.out)[idx] = from_f32<T>(acc);
+    typedef T Tx8 __attribute__((ext_vector_type(8)));
+    if constexpr (sizeof(T) == 2) {
+      Tx8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(acc[e]);
+      *reinterpret_cast<Tx8*>((T*)p.out + pix * p.Cout + co) = o;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ((T*)p.out)[pix * p.Cout + co + e] = from_f32<T>(acc[e]);
+    }
   }
 }
 
@@ -258,13 +315,45 @@ int timestep_embedding(const int64_t* t, float* out, int B, int dim, float max_p
   return SDMI_OK;
 }
 
+constexpr size_t SMALL_LINEAR_MAX_LDS = 144 * 1024;
+int elementwise_init();
+
 int small_linear(const float* x, const float* W, const float* bias, float* y, int M, int K, int N, int act_in,
                  int act_out, hipStream_t s) {
   SDMI_REQUIRE(x && W && y && M > 0 && K > 0 && N > 0, "small_linear: bad arguments");
-  constexpr int MB = 8;
-  dim3 grid((N + 3) / 4, (M + MB - 1) / MB);
-  hipLaunchKernelGGL(small_linear_kernel<MB>, grid, dim3(256), 0, s, x, W, bias, y, M, K, N, act_in, act_out);
+  SDMI_REQUIRE(K % 4 == 0, "small_linear: K=%d must be a multiple of 4", K);
+  SDMI_TRY(elementwise_init());
+  const int per_block = 4 * SL_NPW * SL_PASSES;
+  if (M <= 8) {
+    SDMI_REQUIRE((size_t)8 * K * 4 <= SMALL_LINEAR_MAX_LDS, "small_linear: K=%d too large", K);
+    hipLaunchKernelGGL(small_linear_kernel<8>, dim3((N + per_block - 1) / per_block, 1), dim3(256), 8 * K * 4, s, x,
+                       W, bias, y, M, K, N, act_in, act_out);
+  } else {
+    SDMI_REQUIRE((size_t)16 * K * 4 <= SMALL_LINEAR_MAX_LDS, "small_linear: K=%d too large", K);
+    hipLaunchKernelGGL(small_linear_kernel<16>, dim3((N + per_block - 1) / per_block, (M + 15) / 16), dim3(256),
+                       16 * K * 4, s, x, W, bias, y, M, K, N, act_in, act_out);
+  }
   SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+constexpr size_t IN_CONV_MAX_LDS = 144 * 1024;
+
+// Raise the dynamic-LDS limit of the first-convolution kernels once, outside of stream capture.
+int elementwise_init() {
+  static bool done = false;
+  if (done) return SDMI_OK;
+  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)in_conv_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)IN_CONV_MAX_LDS));
+  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)in_conv_kernel<half_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)IN_CONV_MAX_LDS));
+  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)in_conv_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)IN_CONV_MAX_LDS));
+  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)small_linear_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)SMALL_LINEAR_MAX_LDS));
+  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)small_linear_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)SMALL_LINEAR_MAX_LDS));
+  done = true;
   return SDMI_OK;
 }
 
@@ -276,9 +365,16 @@ int in_conv(const InConvArgs& a, hipStream_t s) {
   }
   SDMI_REQUIRE(a.src[0] && a.w && a.bias && a.out && p.Cin > 0 && p.Cin <= 64, "in_conv: bad arguments");
   p.w = a.w; p.bias = a.bias; p.out = a.out; p.B = a.B; p.H = a.H; p.W = a.W; p.Cout = a.Cout;
-  const size_t total = (size_t)a.B * a.H * a.W * a.Cout;
+  SDMI_REQUIRE(a.Cout % 8 == 0 && a.Cout <= 2048, "in_conv: Cout=%d must be a multiple of 8, at most 2048", a.Cout);
+  const size_t lds = (size_t)9 * p.Cin * a.Cout * sizeof(float);
+  SDMI_REQUIRE(lds <= IN_CONV_MAX_LDS, "in_conv: %d x %d weights do not fit in LDS", p.Cin, a.Cout);
+  SDMI_TRY(elementwise_init());
+  const size_t npix = (size_t)a.B * a.H * a.W;
+  const int ppb = 256 / (a.Cout / 8);
+  size_t blocks = (npix + ppb - 1) / ppb;
+  if (blocks > 1024) blocks = 1024;
   SDMI_DISPATCH_DTYPE(a.dtype, T,
-                      hipLaunchKernelGGL(in_conv_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, p));
+                      hipLaunchKernelGGL(in_conv_kernel<T>, dim3((unsigned)blocks), dim3(256), lds, s, p));
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

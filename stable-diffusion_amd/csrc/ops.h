@@ -83,6 +83,7 @@ struct AttentionArgs {
 };
 int attention(const AttentionArgs& a, hipStream_t stream);
 int attention_init();   // one-time kernel attribute setup; call outside stream capture
+int elementwise_init(); // same, for the first-convolution kernel
 
 // ---- small / elementwise ---------------------------------------------------------------------
 // emb[b][:] = [cos(t*f) | sin(t*f)], f_k = exp(-ln(max_period) k / half)            (fp32 out)

@@ -263,6 +263,7 @@ struct sdmi_unet {
     if (finalized) { sdmi_set_error("finalize: already finalized"); return SDMI_ESTATE; }
     SDMI_TRY(store.check_complete(specs));
     SDMI_TRY(conv_gemm_init());
+    SDMI_TRY(elementwise_init());
     SDMI_TRY(attention_init());
     std::vector<std::string> packed_keys;
     auto P = [&](PackedConv* pc, const std::string& prefix, int cout, int cin, int taps, bool bias = true) {

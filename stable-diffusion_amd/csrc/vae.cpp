@@ -112,6 +112,7 @@ struct sdmi_vae_decoder {
     if (finalized) { sdmi_set_error("finalize: already finalized"); return SDMI_ESTATE; }
     SDMI_TRY(store.check_complete(specs));
     SDMI_TRY(conv_gemm_init());
+    SDMI_TRY(elementwise_init());
     std::vector<std::string> drop;
     auto P = [&](PackedConv* pc, const std::string& prefix, int cout, int cin, int taps) {
       pc->cin = cin; pc->cout = cout; pc->taps = taps;

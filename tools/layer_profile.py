@@ -11,8 +11,11 @@ _lib = importlib.import_module("stable-diffusion_amd._lib")
 
 
 def main():
+    vae = len(sys.argv) > 1 and sys.argv[1] == "vae"
+    if vae:
+        sys.argv.pop(1)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-    out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", f"layers_b{B}.csv")
+    out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", f"layers_{'vae_' if vae else ''}b{B}.csv")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     lib = _lib.lib()
     model = pipeline.build_synthetic_model(4, "crossattn", "fp16")
@@ -22,14 +25,21 @@ def main():
     ctx = torch.cat(pipeline.synthetic_conditioning(B // 2)) if B >= 2 else pipeline.synthetic_conditioning(1)[0]
     t = torch.full((B,), 981, dtype=torch.int64, device="cuda")
     o = torch.empty_like(x)
+    fwd = (lambda: model.decode_first_stage(x)) if vae else (lambda: unet(x, t, context=ctx, out=o))
     for _ in range(3):
-        unet(x, t, context=ctx, out=o)
+        fwd()
     torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(3):
+        fwd()
+    torch.cuda.synchronize()
+    print(f"wall per forward: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms")
     lib.sdmi_prof_reset()
     lib.sdmi_prof_enable(1)
     reps = 5
     for _ in range(reps):
-        unet(x, t, context=ctx, out=o)
+        fwd()
     torch.cuda.synchronize()
     lib.sdmi_prof_enable(0)
     _lib.check(lib.sdmi_prof_dump(out.encode()), "prof_dump")

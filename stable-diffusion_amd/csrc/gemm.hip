@@ -146,19 +146,21 @@ __device__ __forceinline__ void store_wave_tile(const GemmParams& p, f32x4 (&acc
     }
     return;
   }
-  if (p.geglu) {
-    const int obase = n_wave / 2 + fq * 4;
+  if constexpr (NI % 2 == 0) {
+    if (p.geglu) {
+      const int obase = n_wave / 2 + fq * 4;
 #pragma unroll
-    for (int j = 0; j < MJ; ++j) {
-      const int m = m_lane + j * 16;
-      if (m >= p.M) continue;
+      for (int j = 0; j < MJ; ++j) {
+        const int m = m_lane + j * 16;
+        if (m >= p.M) continue;
 #pragma unroll
-      for (int i = 0; i < NI; i += 2) {
-        const int n = nbase + i * 16;
-        if (n < p.N) epilogue_store_geglu<T>(p, m, n, n + 16, obase + (i / 2) * 16, acc[i][j], acc[i + 1][j]);
+        for (int i = 0; i < NI; i += 2) {
+          const int n = nbase + i * 16;
+          if (n < p.N) epilogue_store_geglu<T>(p, m, n, n + 16, obase + (i / 2) * 16, acc[i][j], acc[i + 1][j]);
+        }
       }
+      return;
     }
-    return;
   }
 #pragma unroll
   for (int j = 0; j < MJ; ++j) {
@@ -421,38 +423,48 @@ __global__ __launch_bounds__(S::NTHREADS) void conv_gemm_kernel(GemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Large-tile kernel: 256(m) x 64*NH(n) per 512-thread workgroup, one workgroup per CU.
+// Large-tile kernel: 256(m) x 32*NFW(n) per 512-thread workgroup, one workgroup per CU.
 //
 // A 128x128 tile moves 32 KiB of operands L2 -> LDS per 2.1 MFLOP, which is what bounds the kernel
 // above; a 256x320 tile moves 72 KiB per 10.5 MFLOP, less than half of that per flop.  With a single
 // workgroup on the CU the overlap of LDS traffic and MFMAs has to be built by hand: the 8 waves form
 // two groups of four (one wave of each group per SIMD) that run the same program one segment
-// apart.  A K-tile (64 deep) is four phases per wave; a phase is a read segment (ds_read of the
-// phase's fragments + a share of the next tile's LDS-DMA, retired with lgkmcnt(0)), a barrier, an
-// MFMA segment (4 x NH MFMAs), a barrier.  Group 1 enters the loop one barrier late, so in every
-// segment one group feeds the matrix cores while the other one reads.
+// apart.  A K-tile (64 deep) is 2 NPH phases per wave; a phase is a read segment (ds_read of the
+// phase's fragments + a share of a later tile's LDS-DMA, retired with lgkmcnt(0)), a barrier, an
+// MFMA segment (4 x NFW/NPH MFMAs), a barrier.  Group 1 enters the loop one barrier late, so in
+// every segment one group feeds the matrix cores while the other one reads.
 //
-// Wave (wr = wid & 3, grp = wid >> 2) owns rows wr*64..+63 and columns grp*32*NH.. (2 NH fragments); phase
-// (ks, h) multiplies k-step ks of the tile into the wave's column half h (NH fragments).
+// Wave (wr = wid & 3, grp = wid >> 2) owns rows wr*64..+63 and columns grp*16*NFW.. (NFW fragments);
+// phase (ks, h) multiplies k-step ks of the tile into column part h (NFW/NPH fragments).
 //
-// Hazards.  Stage s of K-tile t is read in t's eight segments; the last reads (group 1, phase 3)
+// Shapes: NFW 10 / NPH 2 (256x320) and NFW 8 / NPH 2 (256x256) with two LDS stages; NFW 5 / NPH 1
+// (256x160, for layers with too few 256x320 tiles to fill the chip) with three.
+//
+// Hazards.  The stage of K-tile t is read in t's segments; the last reads (group 1, last phase)
 // retire before the barrier that opens group 0's first segment of tile t+1, and the DMA of tile
-// t+2 into that stage is issued no earlier than that segment.  Every wave waits for its own DMA of
-// tile t+1 (vmcnt(0)) before the last barrier that precedes group 0's first read of it.
-template <int NH_> struct PPShape {
-  static constexpr int NH = NH_;
-  static constexpr int BM = 256, BN = 64 * NH, NTHREADS = 512;
-  static constexpr int AP = 4, WP = BN / 64;                        // 1-KiB DMA pieces per wave and tile
+// t+NSTAGE into that stage is issued no earlier than that segment.  Every wave waits for its own
+// DMA of tile t+1 (counted vmcnt: with three stages tile t+2 stays in flight) before the last
+// barrier that precedes group 0's first read of it.
+template <int NFW_, int NPH_, int NSTAGE_> struct PPShape {
+  static constexpr int NFW = NFW_, NPH = NPH_, NSTAGE = NSTAGE_;
+  static constexpr int NFP = NFW / NPH;                             // fragments per phase
+  static constexpr int BM = 256, BN = 32 * NFW, NTHREADS = 512;
+  static constexpr int AP = 4;                                      // 1-KiB activation pieces per wave and tile
+  static constexpr int WPT = BN / 8, WP_LO = WPT / 8, WP_REM = WPT % 8;   // weight pieces: waves < WP_REM take one more
+  static constexpr int WP_MAX = WP_LO + (WP_REM ? 1 : 0);
   static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
-  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
-  static_assert(BN % 64 == 0, "weight pieces must divide evenly over 8 waves");
+  static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
+  static_assert(NFW % NPH == 0 && (NSTAGE == 2 || NSTAGE == 3), "unsupported shape");
+  static_assert(LDS_BYTES <= 160 * 1024, "stages do not fit in LDS");
 };
+typedef PPShape<10, 2, 2> PP320;
+typedef PPShape<8, 2, 2> PP256;
+typedef PPShape<5, 1, 3> PP160;
 
-template <typename T, int NH>
+template <typename T, typename S>
 __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
-  typedef PPShape<NH> S;
   static_assert(sizeof(T) == 2, "16-bit operands only");
-  constexpr int BK = 64, AP = S::AP, WP = S::WP;
+  constexpr int BK = 64, AP = S::AP, NFW = S::NFW, NFP = S::NFP, NPH = S::NPH, NSTAGE = S::NSTAGE;
   typedef typename Frag<T>::type frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -494,7 +506,9 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   }
   // weight rows: the launcher guarantees N % BN == 0, so every row exists.  One 32-bit byte offset per
   // lane; the pieces of a tile differ by a wave-uniform stride (scalar base + vector offset loads).
-  unsigned wofs = (unsigned)(((size_t)(n0 + wid * WP * 8 + lrow) * p.K + (size_t)kt_begin * BK) * sizeof(T)) + sc * 16;
+  const int wp_first = wid * S::WP_LO + min(wid, S::WP_REM);           // first weight piece of this wave
+  const bool wp_extra = S::WP_REM != 0 && wid < S::WP_REM;             // ... and whether it has WP_LO + 1
+  unsigned wofs = (unsigned)(((size_t)(n0 + wp_first * 8 + lrow) * p.K + (size_t)kt_begin * BK) * sizeof(T)) + sc * 16;
   const size_t wpitch8 = (size_t)8 * p.K * sizeof(T);
   const int tiles_c0 = p.c0 / BK, tiles_c1 = p.c1 / BK, tiles_tap = tiles_c0 + tiles_c1;
   const int Hup = p.up ? 2 * p.Hin : p.Hin, Wup = p.up ? 2 * p.Win : p.Win;
@@ -528,8 +542,8 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
     const int src = rem >= tiles_c0 ? 1 : 0;
     set_segment(tap, src, src ? rem - tiles_c0 : rem);
   }
-  auto prefetch_a = [&](int buf) {
-    char* abuf = smem + buf * S::STAGE_BYTES;
+  auto prefetch_a = [&](int stage) {
+    char* abuf = smem + stage * S::STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       glds16(acur[i], abuf + (wid * AP + i) * 1024);
@@ -542,23 +556,29 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
       if (tap < p.taps) set_segment(tap, src, 0);
     }
   };
-  auto prefetch_w = [&](int buf) {
-    char* wbuf = smem + buf * S::STAGE_BYTES + S::A_BYTES;
+  auto prefetch_w = [&](int stage) {
+    char* wbuf = smem + stage * S::STAGE_BYTES + S::A_BYTES + wp_first * 1024;
 #pragma unroll
-    for (int i = 0; i < WP; ++i) glds16(p.w + i * wpitch8 + wofs, wbuf + (wid * WP + i) * 1024);
+    for (int i = 0; i < S::WP_LO; ++i) glds16(p.w + i * wpitch8 + wofs, wbuf + i * 1024);
+    if (wp_extra) glds16(p.w + S::WP_LO * wpitch8 + wofs, wbuf + S::WP_LO * 1024);
     wofs += 128;
+  };
+  // wait until at most one tile's worth of this wave's DMA is still in flight (three-stage ring)
+  auto wait_keep_one_tile = [&]() {
+    if (wp_extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + S::WP_LO + 1) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + S::WP_LO) : "memory");
   };
 
   const int frow = lane & 15, fq = lane >> 4;
   // The accumulators start from the per-column bias and the per-(sample, column) time-embedding term
   // (when this launch owns the epilogue): their loads overlap the first tile's DMA and the epilogue
   // is left with the residual only.
-  f32x4 acc[2 * NH][4];
+  f32x4 acc[NFW][4];
   const bool own_epilogue = p.partial == nullptr;
   {
     const int ncol = n0 + grp * (S::BN / 2) + fq * 4;
 #pragma unroll
-    for (int i = 0; i < 2 * NH; ++i) {
+    for (int i = 0; i < NFW; ++i) {
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
       if (own_epilogue && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + ncol + i * 16);
 #pragma unroll
@@ -570,90 +590,77 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
         const int m = min(m0 + wr * 64 + j * 16 + frow, p.M - 1);
         const float* ra = p.rowadd + (size_t)(m / hw) * p.ldra + ncol;
 #pragma unroll
-        for (int i = 0; i < 2 * NH; ++i) acc[i][j] += *reinterpret_cast<const f32x4*>(ra + i * 16);
+        for (int i = 0; i < NFW; ++i) acc[i][j] += *reinterpret_cast<const f32x4*>(ra + i * 16);
         __builtin_amdgcn_sched_barrier(0);        // one row group's loads in flight at a time (registers)
       }
     }
   }
   const int sw = frow & 7;
-  const int coff0 = (fq ^ sw) * 16, coff1 = ((4 + fq) ^ sw) * 16;
   const int a_base = (wr * 64 + frow) * 128;
   const int w_base = S::A_BYTES + (grp * (S::BN / 2) + frow) * 128;
 
-  frag_t af[4], wf[NH];
+  frag_t af[4], wf[NFP];
 
-#define PP_READ_A(SB, COFF)                                                                     \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
-      af[j] = *reinterpret_cast<const frag_t*>((SB) + a_base + j * 2048 + (COFF));
-#define PP_READ_W(SB, H, COFF)                                                                  \
-  _Pragma("unroll") for (int i = 0; i < NH; ++i)                                                 \
-      wf[i] = *reinterpret_cast<const frag_t*>((SB) + w_base + ((H) * NH + i) * 2048 + (COFF));
-// end of a read segment: fragments in registers, then hand the matrix cores over
-#define PP_READ_DONE()                                                                          \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
-  __builtin_amdgcn_sched_barrier(0);                                                            \
-  __builtin_amdgcn_s_barrier();                                                                 \
-  __builtin_amdgcn_sched_barrier(0);
-#define PP_MFMA(H)                                                                              \
-  __builtin_amdgcn_s_setprio(1);                                                                \
-  _Pragma("unroll") for (int i = 0; i < NH; ++i)                                                 \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                              \
-          acc[(H) * NH + i][j] = mma(wf[i], af[j], acc[(H) * NH + i][j]);                       \
-  __builtin_amdgcn_s_setprio(0);
-#define PP_MFMA_DONE()                                                                          \
-  __builtin_amdgcn_sched_barrier(0);                                                            \
-  __builtin_amdgcn_s_barrier();                                                                 \
-  __builtin_amdgcn_sched_barrier(0);
-
-  // ---- prologue: tile 0 into stage 0, visible to everyone; then stagger the groups ------------
-  prefetch_a(0);
-  prefetch_w(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- prologue: the first NSTAGE-1 tiles are put in flight, tile 0 is made visible to everyone,
+  // then the groups are staggered ----------------------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < NSTAGE - 1; ++t)
+    if (t < nk) { prefetch_a(t); prefetch_w(t); }
+  if (NSTAGE == 3 && nk > 1) wait_keep_one_tile();
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (grp == 1) __builtin_amdgcn_s_barrier();
 
+  int st_rd = 0, st_wr = NSTAGE - 1;          // stage of the tile being multiplied / of the tile being fetched
   for (int kt = 0; kt < nk; ++kt) {
-    const char* sb = smem + (kt & 1) * S::STAGE_BYTES;
-    const int nb = (kt + 1) & 1;
-    const bool more = kt + 1 < nk;
-    // phase 0: k-step 0, column half 0
-    PP_READ_A(sb, coff0)
-    PP_READ_W(sb, 0, coff0)
-    if (more) prefetch_a(nb);
-    PP_READ_DONE()
-    PP_MFMA(0)
-    PP_MFMA_DONE()
-    // phase 1: k-step 0, column half 1
-    PP_READ_W(sb, 1, coff0)
-    if (more) prefetch_w(nb);
-    PP_READ_DONE()
-    PP_MFMA(1)
-    PP_MFMA_DONE()
-    // phase 2: k-step 1, column half 0
-    PP_READ_A(sb, coff1)
-    PP_READ_W(sb, 0, coff1)
-    PP_READ_DONE()
-    PP_MFMA(0)
-    PP_MFMA_DONE()
-    // phase 3: k-step 1, column half 1; the next tile's DMA is retired before the barrier that
-    // precedes group 0's first read of it
-    PP_READ_W(sb, 1, coff1)
-    if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PP_READ_DONE()
-    PP_MFMA(1)
-    if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PP_MFMA_DONE()
+    const char* sb = smem + st_rd * S::STAGE_BYTES;
+    const bool more = kt + NSTAGE - 1 < nk;           // a tile to put in flight during this one
+    const bool keep = NSTAGE == 3 && kt + 2 < nk;     // ... that may stay in flight past the end of this one
+#pragma unroll
+    for (int ph = 0; ph < 2 * NPH; ++ph) {
+      const int ks = ph / NPH, h = ph % NPH;
+      const int coff = ((4 * ks + fq) ^ sw) * 16;
+      // read segment
+      if (h == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const frag_t*>(sb + a_base + j * 2048 + coff);
+      }
+#pragma unroll
+      for (int i = 0; i < NFP; ++i)
+        wf[i] = *reinterpret_cast<const frag_t*>(sb + w_base + (h * NFP + i) * 2048 + coff);
+      if (ph == 0 && more) prefetch_a(st_wr);
+      if (ph == 1 && more) prefetch_w(st_wr);
+      if (ph == 2 * NPH - 1 && grp == 1) {      // the next tile's DMA is retired before the barrier that
+        if (keep) wait_keep_one_tile();         // precedes group 0's first read of it
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // MFMA segment
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < NFP; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[h * NFP + i][j] = mma(wf[i], af[j], acc[h * NFP + i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      if (ph == 2 * NPH - 1 && grp == 0) {
+        if (keep) wait_keep_one_tile();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    st_rd = st_rd + 1 == NSTAGE ? 0 : st_rd + 1;
+    st_wr = st_wr + 1 == NSTAGE ? 0 : st_wr + 1;
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
-#undef PP_READ_A
-#undef PP_READ_W
-#undef PP_READ_DONE
-#undef PP_MFMA
-#undef PP_MFMA_DONE
 
   if (p.dbg & 8) {      // timing experiments: no epilogue (accumulators kept alive)
 #pragma unroll
-    for (int i = 0; i < 2 * NH; ++i)
+    for (int i = 0; i < NFW; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
@@ -663,24 +670,24 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   const int m_wave = m0 + wr * 64, n_wave = n0 + grp * (S::BN / 2);
   if (p.wide_store) {
     // all stage reads and DMAs are retired behind the last barrier: the stages are free
-    float* strip = reinterpret_cast<float*>(smem + wid * (S::LDS_BYTES / 8));
+    float* strip = reinterpret_cast<float*>(smem + wid * (16 * (16 * NFW + 4) * 4));
+    static_assert(8 * 16 * (16 * NFW + 4) * 4 <= S::LDS_BYTES, "strips do not fit");
     if (p.partial) {
       pe.resid = nullptr;                                            // applied by the reduction pass
-      store_wave_tile_lds<T, float, 2 * NH, false>(pe, acc, strip, p.partial + (size_t)blockIdx.y * p.M * p.N, p.N,
-                                                   m_wave, n_wave, lane);
+      store_wave_tile_lds<T, float, NFW, false>(pe, acc, strip, p.partial + (size_t)blockIdx.y * p.M * p.N, p.N,
+                                                m_wave, n_wave, lane);
     } else if (p.out_f32) {
-      store_wave_tile_lds<T, float, 2 * NH, false>(pe, acc, strip, reinterpret_cast<float*>(p.out), p.ldo, m_wave,
-                                                   n_wave, lane);
-    } else if (p.geglu) {
-      store_wave_tile_lds<T, T, 2 * NH, true>(pe, acc, strip, reinterpret_cast<T*>(p.out), p.ldo, m_wave, n_wave,
-                                              lane);
+      store_wave_tile_lds<T, float, NFW, false>(pe, acc, strip, reinterpret_cast<float*>(p.out), p.ldo, m_wave,
+                                                n_wave, lane);
+    } else if (NFW % 2 == 0 && p.geglu) {
+      if constexpr (NFW % 2 == 0)
+        store_wave_tile_lds<T, T, NFW, true>(pe, acc, strip, reinterpret_cast<T*>(p.out), p.ldo, m_wave, n_wave, lane);
     } else {
-      store_wave_tile_lds<T, T, 2 * NH, false>(pe, acc, strip, reinterpret_cast<T*>(p.out), p.ldo, m_wave, n_wave,
-                                               lane);
+      store_wave_tile_lds<T, T, NFW, false>(pe, acc, strip, reinterpret_cast<T*>(p.out), p.ldo, m_wave, n_wave, lane);
     }
     return;
   }
-  store_wave_tile<T, 2 * NH, 4>(pe, acc, m_wave + frow, n_wave, fq);
+  store_wave_tile<T, NFW, 4>(pe, acc, m_wave + frow, n_wave, fq);
 }
 
 // split-K second pass: sum the fp32 slabs and run the same epilogue.  One thread per 4 columns.
@@ -719,10 +726,12 @@ int set_lds_limits() {
   SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_kernel<T, ShapeSmall>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, ShapeSmall::LDS_BYTES));
   if constexpr (sizeof(T) == 2) {
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, 5>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, PPShape<5>::LDS_BYTES));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, 4>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, PPShape<4>::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP320>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP320::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP256>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP256::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP160::LDS_BYTES));
   }
   return SDMI_OK;
 }
@@ -751,19 +760,20 @@ namespace {
 // the workgroups are dealt to the CUs in rounds (512 small blocks or 256 large ones per round), a
 // round takes (K-tiles per split) x (time of one K-tile of that shape), and split-K adds the slab
 // round trip through HBM plus a launch.  The K-tile times are measured on MI355X with full grids.
-enum { KIND_SMALL = 0, KIND_PP5 = 1, KIND_PP4 = 2 };
+enum { KIND_SMALL = 0, KIND_PP320 = 1, KIND_PP256 = 2, KIND_PP160 = 3 };
 struct Plan { int kind, splits; };
 
-// SDMI_GEMM_SHAPE (tests, experiments; read on every call): 1 = 128x128 tiles only, 2 = large tiles
-// wherever they are legal.
+// SDMI_GEMM_SHAPE (tests, experiments; read on every call): 1 = 128x128 tiles only, 2 = 256x320 /
+// 256x256 tiles wherever they are legal, 3 = 256x160 tiles wherever they are legal.
 int forced_kind() {
   const char* e = getenv("SDMI_GEMM_SHAPE");
   return e ? atoi(e) : 0;
 }
 
 constexpr double T_KT_SMALL_US = 1.40;    // 128x128x64 K-tile, two blocks per CU
-constexpr double T_KT_PP5_US = 2.10;      // 256x320x64 K-tile, one block per CU
-constexpr double T_KT_PP4_US = 1.75;      // 256x256x64
+constexpr double T_KT_PP320_US = 2.10;    // 256x320x64 K-tile, one block per CU
+constexpr double T_KT_PP256_US = 1.75;    // 256x256x64
+constexpr double T_KT_PP160_US = 1.20;    // 256x160x64
 
 double split_cost_us(int M, int N, int splits) {
   if (splits <= 1) return 0.0;
@@ -781,7 +791,7 @@ int small_splits(int M, int N, int nkt) {
   return s < 1 ? 1 : s;
 }
 
-Plan make_plan(int M, int N, int K, int dtype) {
+Plan make_plan(int M, int N, int K, int dtype, bool geglu) {
   const int BK = dtype == SDMI_F32 ? 32 : 64;
   const int nkt = K / BK;
   Plan best;
@@ -795,16 +805,17 @@ Plan make_plan(int M, int N, int K, int dtype) {
     best_t = (double)((blocks + 511) / 512) * (per + 1.5) * T_KT_SMALL_US + split_cost_us(M, N, best.splits);
   }
   bool found = false;
-  for (int kind = KIND_PP5; kind <= KIND_PP4; ++kind) {
-    const int bn = kind == KIND_PP5 ? 320 : 256;
+  for (int kind = KIND_PP320; kind <= KIND_PP160; ++kind) {
+    const int bn = kind == KIND_PP320 ? 320 : (kind == KIND_PP256 ? 256 : 160);
     if (N % bn != 0) continue;
-    const double tk = kind == KIND_PP5 ? T_KT_PP5_US : T_KT_PP4_US;
+    if (kind == KIND_PP160 && (geglu || forced_kind() == 2)) continue;      // odd fragment count: no (value, gate) pairs
+    const double tk = kind == KIND_PP320 ? T_KT_PP320_US : (kind == KIND_PP256 ? T_KT_PP256_US : T_KT_PP160_US);
     const long tiles = (long)((M + 255) / 256) * (N / bn);
     for (int s = 1; s <= 16; ++s) {
       if (s > 1 && nkt / s < 8) break;
       const int per = (nkt + s - 1) / s;
       const double t = (double)((tiles * s + 255) / 256) * (per + 3.0) * tk + split_cost_us(M, N, s);
-      if (t < best_t || (forced_kind() == 2 && !found)) {
+      if (t < best_t || (forced_kind() == 2 && !found) || (forced_kind() == 3 && kind == KIND_PP160 && best.kind != kind)) {
         best_t = t; best.kind = kind; best.splits = s; found = true;
       }
     }
@@ -813,13 +824,12 @@ Plan make_plan(int M, int N, int K, int dtype) {
 }
 
 // kernel for an explicit split count (callers size the slab with conv_gemm_pick_splits)
-int pick_kind(int M, int N, int K, int dtype) { return make_plan(M, N, K, dtype).kind; }
+int pick_kind(int M, int N, int K, int dtype, bool geglu) { return make_plan(M, N, K, dtype, geglu).kind; }
 
-template <typename T, int NH>
+template <typename T, typename S>
 void launch_pp(GemmParams& p, int splits, hipStream_t stream) {
-  typedef PPShape<NH> S;
   p.tiles_m = (p.M + S::BM - 1) / S::BM; p.tiles_n = p.N / S::BN;
-  hipLaunchKernelGGL((conv_gemm_pp_kernel<T, NH>), dim3(p.tiles_m * p.tiles_n, splits), dim3(S::NTHREADS),
+  hipLaunchKernelGGL((conv_gemm_pp_kernel<T, S>), dim3(p.tiles_m * p.tiles_n, splits), dim3(S::NTHREADS),
                      S::LDS_BYTES, stream, p);
 }
 
@@ -863,7 +873,7 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
     p.dbg = dbg;
   }
   p.zero = g_zero_page;
-  const int kind = pick_kind(p.M, p.N, p.K, a.dtype);
+  const int kind = pick_kind(p.M, p.N, p.K, a.dtype, a.geglu != 0);
   p.wide_store = a.ldo % 8 == 0 && (!a.resid || a.ldr % 8 == 0) && ((uintptr_t)a.out % 16 == 0) &&
                  (!a.resid || (uintptr_t)a.resid % 16 == 0) && (!p.partial || (uintptr_t)p.partial % 16 == 0) &&
                  !(p.out_f32 && p.geglu) && !(p.dbg & 16);
@@ -875,8 +885,9 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
                    ((double)p.M * p.K / (p.taps == 9 ? 9 : 1) + (double)p.N * p.K + (double)p.M * p.N) * sizeof(T),
                    label);
     if constexpr (sizeof(T) == 2) {
-      if (kind == KIND_PP5) launch_pp<T, 5>(p, splits, stream);
-      else if (kind == KIND_PP4) launch_pp<T, 4>(p, splits, stream);
+      if (kind == KIND_PP320) launch_pp<T, PP320>(p, splits, stream);
+      else if (kind == KIND_PP256) launch_pp<T, PP256>(p, splits, stream);
+      else if (kind == KIND_PP160) launch_pp<T, PP160>(p, splits, stream);
     }
     if (kind == KIND_SMALL || sizeof(T) != 2) {
       typedef ShapeSmall S;
@@ -903,4 +914,4 @@ int conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
   return SDMI_OK;
 }
 
-int conv_gemm_pick_splits(int M, int N, int K, int dtype) { return make_plan(M, N, K, dtype).splits; }
+int conv_gemm_pick_splits(int M, int N, int K, int dtype, bool geglu) { return make_plan(M, N, K, dtype, geglu).splits; }

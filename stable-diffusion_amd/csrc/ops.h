@@ -47,7 +47,7 @@ struct ConvGemmArgs {
 int conv_gemm(const ConvGemmArgs& a, hipStream_t stream);
 int conv_gemm_init();   // one-time kernel attribute setup; call outside stream capture
 // smallest split count worth using for this shape on a 256-CU part (1 = no split)
-int conv_gemm_pick_splits(int M, int N, int K, int dtype);
+int conv_gemm_pick_splits(int M, int N, int K, int dtype, bool geglu = false);
 
 // ---- normalisation ---------------------------------------------------------------------------
 struct GroupNormArgs {

@@ -394,7 +394,7 @@ struct sdmi_unet {
     g.B = B; g.Hin = Hin; g.Win = Win; g.Ho = Ho; g.Wo = Wo; g.taps = pc.taps; g.stride = stride; g.up = up;
     g.N = pc.cout; g.geglu = geglu; g.dtype = dtype;
     const int M = B * Ho * Wo, K = pc.taps * (c0 + (a1 ? c1 : 0));
-    g.splits = conv_gemm_pick_splits(M, pc.cout, K, dtype);
+    g.splits = conv_gemm_pick_splits(M, pc.cout, K, dtype, geglu != 0);
     if (g.splits > 1) g.partial = (float*)ws.get("splitk", (size_t)g.splits * M * pc.cout * 4);
     if (ws.dry) return SDMI_OK;
     return conv_gemm(g, s);

@@ -108,9 +108,25 @@ def test_conv2d_large_tiles(ops, dt, case, monkeypatch):
 
 
 @pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("case", PP_CASES, ids=[c[0] for c in PP_CASES])
+def test_conv2d_tiles_256x160(ops, dt, case, monkeypatch):
+    """Same cases through the three-stage 256 x 160 shape (taken where N is a multiple of 160)."""
+    monkeypatch.setenv("SDMI_GEMM_SHAPE", "3")
+    test_conv2d(ops, dt, case)
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("shape", ["2", "3"])
+def test_large_tiles_long_k(ops, dt, shape, monkeypatch):
+    """Many K-tiles across taps and both concat sources: ring wrap-around and segment changes."""
+    monkeypatch.setenv("SDMI_GEMM_SHAPE", shape)
+    test_conv2d(ops, dt, ("pp_long_k", 1, 16, 16, 448, 192, 320, 9, 1, 0, 1))
+    test_conv2d(ops, dt, ("pp_long_k_split", 1, 16, 16, 448, 192, 320, 9, 1, 0, 5))
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
 def test_large_tiles_epilogues(ops, dt, monkeypatch):
     """bias + time-embedding row add + residual and the GEGLU gate through the large-tile kernel."""
-    monkeypatch.setenv("SDMI_GEMM_SHAPE", "2")
     B, H, W, C, Cout = 2, 16, 16, 128, 320
     x = q(rnd("ppepi.x", (B, C, H, W)), dt)
     w = q(rnd("ppepi.w", (Cout, C, 3, 3), -0.05, 0.05), dt)
@@ -119,9 +135,12 @@ def test_large_tiles_epilogues(ops, dt, monkeypatch):
     res = q(rnd("ppepi.res", (B, Cout, H, W)), dt)
     ref = F.conv2d(x, w, b, padding=1) + emb[:, :, None, None] + res
     wp = ops.pack_weight(w.cuda(), dt)
-    for splits in (1, 2):
-        y = ops.conv2d(nhwc(x, dt), wp, b.cuda(), taps=9, rowadd=emb.cuda(), resid=nhwc(res, dt), splits=splits)
-        assert max_rel_err(nchw(y), ref) < TOL[dt], splits
+    for shape in ("2", "3"):
+        monkeypatch.setenv("SDMI_GEMM_SHAPE", shape)
+        for splits in (1, 2):
+            y = ops.conv2d(nhwc(x, dt), wp, b.cuda(), taps=9, rowadd=emb.cuda(), resid=nhwc(res, dt), splits=splits)
+            assert max_rel_err(nchw(y), ref) < TOL[dt], (shape, splits)
+    monkeypatch.setenv("SDMI_GEMM_SHAPE", "2")
     rows, d = 300, 320                                   # N = 8 d = 2560 = 8 x 320
     x = q(rnd("ppgeglu.x", (rows, d)), dt)
     w = q(rnd("ppgeglu.w", (8 * d, d), -0.1, 0.1), dt)

@@ -184,6 +184,9 @@ int sdmi_prof_reset(void);
 int sdmi_prof_get(const char* kernel_class, double* ms_total, int64_t* launches, double* flops, double* bytes);
 /* Write one CSV line per profiled launch (class, shape label, microseconds, flops, bytes). */
 int sdmi_prof_dump(const char* path);
+/* Mean elapsed time (microseconds) of n empty event brackets on `stream`: the part of a profiled
+ * launch's bracket that is not the kernel. */
+int sdmi_prof_calibrate(int n, void* stream, double* us_per_bracket);
 
 #ifdef __cplusplus
 }

@@ -78,6 +78,7 @@ SIGNATURES = {
     "sdmi_prof_enable": (c_int, [c_int]),
     "sdmi_prof_reset": (c_int, []),
     "sdmi_prof_dump": (c_int, [c_char_p]),
+    "sdmi_prof_calibrate": (c_int, [c_int, c_void_p, P(ctypes.c_double)]),
     "sdmi_prof_get": (c_int, [c_char_p, P(ctypes.c_double), P(c_int64), P(ctypes.c_double), P(ctypes.c_double)]),
 }
 

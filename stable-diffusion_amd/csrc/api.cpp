@@ -82,6 +82,27 @@ int sdmi_prof_get(const char* kernel_class, double* ms_total, int64_t* launches,
   return SDMI_OK;
 }
 
+int sdmi_prof_calibrate(int n, void* stream, double* us_per_bracket) {
+  SDMI_REQUIRE(n > 0 && us_per_bracket, "prof_calibrate: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<hipEvent_t> ev(2 * (size_t)n);
+  for (auto& e : ev) e = prof_event();
+  for (int i = 0; i < n; ++i) {
+    SDMI_CHECK_HIP(hipEventRecord(ev[2 * i], s));
+    SDMI_CHECK_HIP(hipEventRecord(ev[2 * i + 1], s));
+  }
+  SDMI_CHECK_HIP(hipStreamSynchronize(s));
+  double tot = 0.0;
+  for (int i = 0; i < n; ++i) {
+    float t = 0.f;
+    SDMI_CHECK_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+    tot += t;
+  }
+  for (auto& e : ev) g_prof_pool.push_back(e);
+  *us_per_bracket = tot * 1e3 / n;
+  return SDMI_OK;
+}
+
 int sdmi_prof_dump(const char* path) {
   SDMI_REQUIRE(path, "prof_dump: null path");
   SDMI_CHECK_HIP(hipDeviceSynchronize());

@@ -84,6 +84,9 @@ int sdmi_unet_set_context(sdmi_unet* u, const void* ctx, int batch, int ntok, vo
  * The context set by sdmi_unet_set_context must have the same batch. */
 int sdmi_unet_forward(sdmi_unet* u, const void* x, const void* const* concat, const int* concat_channels,
                       int n_concat, const int64_t* t, void* out, int batch, int h, int w, void* stream);
+/* 1: the caller promises that every sample of the following forwards carries the same timestep (the
+ * DDIM loop's torch.full((b,), step), :5308): the time-embedding MLP then runs on t[0] only.  Default 0. */
+int sdmi_unet_set_uniform_timesteps(sdmi_unet* u, int enable);
 /* Bytes of device memory currently held (weights + caches + workspace). */
 int64_t sdmi_unet_device_bytes(const sdmi_unet* u);
 /* 1: replay the forward as a captured HIP graph when shapes and pointers repeat (default), 0: eager. */

@@ -36,22 +36,25 @@ __global__ void timestep_embedding_kernel(const int64_t* t, float* out, int B, i
 // folds the lanes at the end.
 constexpr int SL_NPW = 4;          // weight rows per wave and pass
 constexpr int SL_PASSES = 2;       // passes per wave
+constexpr int SL_THREADS = 1024;   // 16 waves share one LDS copy of x: enough loads in flight per CU
+constexpr int SL_WAVES = SL_THREADS / 64;
 
 template <int MB>
-__global__ __launch_bounds__(256) void small_linear_kernel(const float* x, const float* W, const float* bias,
-                                                           float* y, int M, int K, int N, int act_in, int act_out) {
+__global__ __launch_bounds__(SL_THREADS) void small_linear_kernel(const float* x, const float* W, const float* bias,
+                                                                  float* y, int M, int K, int N, int act_in,
+                                                                  int act_out) {
   extern __shared__ __attribute__((aligned(16))) float sl_x[];          // [MB][K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mb = blockIdx.y * MB;
-  for (int i = tid; i < MB * K; i += 256) {
-    const int m = i / K;
-    float v = mb + m < M ? x[(size_t)(mb + m) * K + (i - m * K)] : 0.f;
-    if (act_in == 1) v = silu_f(v);
-    sl_x[i] = v;
-  }
+  for (int m = 0; m < MB; ++m)
+    for (int k = tid; k < K; k += SL_THREADS) {
+      float v = mb + m < M ? x[(size_t)(mb + m) * K + k] : 0.f;
+      if (act_in == 1) v = silu_f(v);
+      sl_x[m * K + k] = v;
+    }
   __syncthreads();
   for (int pass = 0; pass < SL_PASSES; ++pass) {
-    const int n0 = ((blockIdx.x * SL_PASSES + pass) * 4 + wave) * SL_NPW;
+    const int n0 = ((blockIdx.x * SL_PASSES + pass) * SL_WAVES + wave) * SL_NPW;
     if (n0 >= N) return;
     float acc[SL_NPW][MB];
 #pragma unroll
@@ -323,16 +326,19 @@ int small_linear(const float* x, const float* W, const float* bias, float* y, in
   SDMI_REQUIRE(x && W && y && M > 0 && K > 0 && N > 0, "small_linear: bad arguments");
   SDMI_REQUIRE(K % 4 == 0, "small_linear: K=%d must be a multiple of 4", K);
   SDMI_TRY(elementwise_init());
-  const int per_block = 4 * SL_NPW * SL_PASSES;
-  if (M <= 8) {
-    SDMI_REQUIRE((size_t)8 * K * 4 <= SMALL_LINEAR_MAX_LDS, "small_linear: K=%d too large", K);
-    hipLaunchKernelGGL(small_linear_kernel<8>, dim3((N + per_block - 1) / per_block, 1), dim3(256), 8 * K * 4, s, x,
-                       W, bias, y, M, K, N, act_in, act_out);
-  } else {
-    SDMI_REQUIRE((size_t)16 * K * 4 <= SMALL_LINEAR_MAX_LDS, "small_linear: K=%d too large", K);
-    hipLaunchKernelGGL(small_linear_kernel<16>, dim3((N + per_block - 1) / per_block, (M + 15) / 16), dim3(256),
-                       16 * K * 4, s, x, W, bias, y, M, K, N, act_in, act_out);
+  const int per_block = SL_WAVES * SL_NPW * SL_PASSES;
+  const dim3 block(SL_THREADS);
+#define SL_LAUNCH(MB_)                                                                                    \
+  {                                                                                                       \
+    SDMI_REQUIRE((size_t)(MB_) * K * 4 <= SMALL_LINEAR_MAX_LDS, "small_linear: K=%d too large", K);     \
+    hipLaunchKernelGGL(small_linear_kernel<MB_>, dim3((N + per_block - 1) / per_block, (M + (MB_) - 1) / (MB_)), \
+                       block, (size_t)(MB_) * K * 4, s, x, W, bias, y, M, K, N, act_in, act_out);       \
   }
+  if (M == 1) SL_LAUNCH(1)
+  else if (M <= 2) SL_LAUNCH(2)
+  else if (M <= 8) SL_LAUNCH(8)
+  else SL_LAUNCH(16)
+#undef SL_LAUNCH
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }
@@ -349,6 +355,10 @@ int elementwise_init() {
                                      (int)IN_CONV_MAX_LDS));
   SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)in_conv_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)IN_CONV_MAX_LDS));
+  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)small_linear_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)SMALL_LINEAR_MAX_LDS));
+  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)small_linear_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)SMALL_LINEAR_MAX_LDS));
   SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)small_linear_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)SMALL_LINEAR_MAX_LDS));
   SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)small_linear_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -840,7 +840,7 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   p.a0 = (const char*)a.a0; p.a1 = (const char*)a.a1; p.c0 = a.c0; p.c1 = a.a1 ? a.c1 : 0;
   p.w = (const char*)a.w; p.out = (char*)a.out; p.ldo = a.ldo;
   p.bias = a.bias; p.rowadd = a.rowadd; p.resid = (const char*)a.resid; p.ldr = a.ldr;
-  p.ldra = a.ldra > 0 ? a.ldra : a.N; p.out_f32 = a.out_f32;
+  p.ldra = a.ldra > 0 ? a.ldra : (a.ldra < 0 ? 0 : a.N); p.out_f32 = a.out_f32;     // < 0: one row for every sample
   p.B = a.B; p.Hin = a.Hin; p.Win = a.Win; p.Ho = a.Ho; p.Wo = a.Wo;
   p.taps = a.taps; p.stride = a.stride; p.up = a.up;
   p.M = a.B * a.Ho * a.Wo; p.N = a.N; p.K = a.taps * (p.c0 + p.c1); p.geglu = a.geglu;

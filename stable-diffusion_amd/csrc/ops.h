@@ -27,7 +27,7 @@ struct ConvGemmArgs {
   int ldo = 0;
   const float* bias = nullptr;  // [N] fp32 or null
   const float* rowadd = nullptr;// [B][ldra] fp32 or null: added per sample (time-embedding projection)
-  int ldra = 0;                 // row stride of rowadd (0 = N)
+  int ldra = 0;                 // row stride of rowadd (0 = N, < 0 = every sample reads row 0)
   int out_f32 = 0;              // 1: store fp32 regardless of dtype (attention scores)
   const void* resid = nullptr;  // [M][ldr] (dtype) or null; may alias out
   int ldr = 0;

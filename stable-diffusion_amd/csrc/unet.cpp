@@ -92,11 +92,15 @@ struct sdmi_unet {
   int ctx_batch = 0, ctx_ntok = 0;
   void* ctx_conv = nullptr; size_t ctx_conv_cap = 0;
 
+  // every sample of a forward carries the same timestep (promise of the caller): embedding MLP on one row
+  int uniform_t = 0;
+  int emb_rows = 0;
+
   // graph replay
   int graph_mode = 1;
   struct GraphKey {
     const void* x; const void* c0; const void* c1; const void* t; void* out;
-    int n_concat, cc0, cc1, B, H, W; hipStream_t stream;
+    int n_concat, cc0, cc1, B, H, W, uniform_t; hipStream_t stream;
     bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
   };
   GraphKey gkey; bool ghave = false;
@@ -426,7 +430,8 @@ struct sdmi_unet {
     void* t1 = ws.get("t1", act_bytes(B, H, W, r.cout));
     y->p = ws.get(out_role, act_bytes(B, H, W, r.cout)); y->H = H; y->W = W; y->C = r.cout;
     SDMI_TRY(gn(x0, x1, B, r.gn1_g, r.gn1_b, 1e-5f, 1, nrm, f.s));
-    SDMI_TRY(gemm(nrm, cin, nullptr, 0, r.conv1, t1, r.cout, B, H, W, H, W, 1, 0, emb_all + r.emb_off, emb_total,
+    SDMI_TRY(gemm(nrm, cin, nullptr, 0, r.conv1, t1, r.cout, B, H, W, H, W, 1, 0, emb_all + r.emb_off,
+                  emb_rows == 1 && B > 1 ? -1 : emb_total,
                   nullptr, 0, 0, nullptr, f.s));
     Tensor t1t{t1, H, W, r.cout};
     SDMI_TRY(gn(t1t, nullptr, B, r.gn2_g, r.gn2_b, 1e-5f, 1, nrm, f.s));
@@ -549,11 +554,12 @@ struct sdmi_unet {
     float* temb1 = (float*)ws.get("temb1", (size_t)B * temb * 4);
     float* emb = (float*)ws.get("emb", (size_t)B * temb * 4);
     float* emb_all = (float*)ws.get("emb_all", (size_t)B * emb_total * 4);
+    emb_rows = uniform_t ? 1 : B;          // rows of the embedding tables actually computed
     if (!ws.dry) {
-      SDMI_TRY(timestep_embedding(f.t, temb0, B, cfg.model_channels, 10000.f, f.s));
-      SDMI_TRY(small_linear(temb0, te0_w, te0_b, temb1, B, cfg.model_channels, temb, 0, 1, f.s));
-      SDMI_TRY(small_linear(temb1, te2_w, te2_b, emb, B, temb, temb, 0, 0, f.s));
-      SDMI_TRY(small_linear(emb, emb_w_all, emb_b_all, emb_all, B, temb, emb_total, 1, 0, f.s));
+      SDMI_TRY(timestep_embedding(f.t, temb0, emb_rows, cfg.model_channels, 10000.f, f.s));
+      SDMI_TRY(small_linear(temb0, te0_w, te0_b, temb1, emb_rows, cfg.model_channels, temb, 0, 1, f.s));
+      SDMI_TRY(small_linear(temb1, te2_w, te2_b, emb, emb_rows, temb, temb, 0, 0, f.s));
+      SDMI_TRY(small_linear(emb, emb_w_all, emb_b_all, emb_all, emb_rows, temb, emb_total, 1, 0, f.s));
     }
     std::vector<Tensor> hs;
     Tensor h;
@@ -604,7 +610,7 @@ struct sdmi_unet {
     memset(&k, 0, sizeof(k));
     k.x = f.x; k.c0 = f.n_concat > 0 ? f.concat[0] : nullptr; k.c1 = f.n_concat > 1 ? f.concat[1] : nullptr;
     k.t = f.t; k.out = f.out; k.n_concat = f.n_concat; k.cc0 = f.cc[0]; k.cc1 = f.cc[1];
-    k.B = f.B; k.H = f.H; k.W = f.W; k.stream = nullptr;
+    k.B = f.B; k.H = f.H; k.W = f.W; k.uniform_t = uniform_t; k.stream = nullptr;
     if (!(ghave && k == gkey)) {
       drop_graph();
       // the caller's stream may be the legacy default stream, which cannot be captured: record the
@@ -692,6 +698,12 @@ int sdmi_unet_forward(sdmi_unet* u, const void* x, const void* const* concat, co
 }
 
 int64_t sdmi_unet_device_bytes(const sdmi_unet* u) { return u ? (int64_t)u->mem.bytes : 0; }
+
+int sdmi_unet_set_uniform_timesteps(sdmi_unet* u, int enable) {
+  SDMI_REQUIRE(u, "set_uniform_timesteps: null handle");
+  u->uniform_t = enable ? 1 : 0;
+  return SDMI_OK;
+}
 
 int sdmi_unet_set_graph_mode(sdmi_unet* u, int enable) {
   SDMI_REQUIRE(u, "set_graph_mode: null handle");

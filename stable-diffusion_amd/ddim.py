@@ -189,7 +189,14 @@ class DDIMSampler(object):
             if self.t_val != t_value:
                 self.t_in.fill_(t_value)
                 self.t_val = t_value
-            s.model.apply_model(self.x_in, self.t_in, cond, out=self.eps)
+            # t_in holds one value for every sample (the loop's torch.full((b,), step), :5308): the UNet may
+            # run its time-embedding MLP on a single row
+            unet = s.model.model.diffusion_model
+            unet.set_uniform_timesteps(True)
+            try:
+                s.model.apply_model(self.x_in, self.t_in, cond, out=self.eps)
+            finally:
+                unet.set_uniform_timesteps(False)
             a_t, a_prev, sigma_t, sqrt_1m = s._scalars(index, use_original_steps)
             noise = None
             if sigma_t != 0.:

@@ -131,6 +131,10 @@ class UNetModel:
         # holding the caller's tensor keeps its storage from being recycled under the same address
         self._ctx_ref, self._ctx_version = context, context._version
 
+    def set_uniform_timesteps(self, enable: bool):
+        """Promise that all samples of the following forwards share one timestep (sampler loops do)."""
+        check(_lib.lib().sdmi_unet_set_uniform_timesteps(self._h, 1 if enable else 0), "set_uniform_timesteps")
+
     def set_graph_mode(self, enable: bool):
         check(_lib.lib().sdmi_unet_set_graph_mode(self._h, 1 if enable else 0), "set_graph_mode")
 

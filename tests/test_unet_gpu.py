@@ -69,6 +69,26 @@ def test_graph_replay_equals_eager_and_context_switch():
     assert torch.equal(back, second)
 
 
+@pytest.mark.parametrize("dt", ["fp32", "fp16"])
+def test_uniform_timestep_promise_changes_nothing(dt):
+    """With one timestep for every sample the single-row embedding path must give the same bits."""
+    net = device_unet(4, dt)
+    g = golden("g3_unet_c2")
+    x, t, ctx = g["x"].cuda(), g["t"].cuda(), g["ctx"].float().cuda()
+    assert int(t.min()) == int(t.max())
+    for graph in (False, True):
+        net.set_graph_mode(graph)
+        ref = net(x, t, context=ctx).clone()
+        net.set_uniform_timesteps(True)
+        try:
+            out = net(x, t, context=ctx).clone()
+            out2 = net(x, t, context=ctx).clone()
+        finally:
+            net.set_uniform_timesteps(False)
+        assert torch.equal(out, ref) and torch.equal(out2, ref), (dt, graph)
+    net.set_graph_mode(True)
+
+
 def test_errors_are_loud():
     net = device_unet(4, "fp16")
     g = golden("g3_unet_c1")

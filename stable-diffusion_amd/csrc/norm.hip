@@ -12,6 +12,7 @@
 // straddle the seam, which is why statistics are accumulated per channel first.
 #include "ops.h"
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -229,8 +230,10 @@ int launch_gn(const GroupNormArgs& a, hipStream_t stream) {
   SDMI_REQUIRE(nvec <= GN_LDS_SLOTS, "groupnorm: C=%d too wide", p.C);
   const int threads = nvec <= 256 ? nvec * (256 / nvec) : 256;
   const int lanes_pix = nvec <= 256 ? 256 / nvec : 1;
-  // enough strips to fill the chip (>= ~2048 blocks in all), each at least 4 pixels per pixel lane
-  int chunks = (2048 + p.B - 1) / p.B;
+  // about two workgroups per CU in all (more, smaller strips pay the per-block statistics prologue
+  // too often; measured best at 512), each strip at least 4 pixels per pixel lane
+  static const int target_blocks = [] { const char* e = getenv("SDMI_GN_BLOCKS"); return e ? atoi(e) : 512; }();
+  int chunks = (target_blocks + p.B - 1) / p.B;
   const int max_by_work = (p.HW + 4 * lanes_pix - 1) / (4 * lanes_pix);
   if (chunks > max_by_work) chunks = max_by_work;
   if (chunks > GN_MAX_CHUNKS) chunks = GN_MAX_CHUNKS;

@@ -87,6 +87,11 @@ int sdmi_unet_forward(sdmi_unet* u, const void* x, const void* const* concat, co
 /* 1: the caller promises that every sample of the following forwards carries the same timestep (the
  * DDIM loop's torch.full((b,), step), :5308): the time-embedding MLP then runs on t[0] only.  Default 0. */
 int sdmi_unet_set_uniform_timesteps(sdmi_unet* u, int enable);
+/* 1: the caller promises that in the following forwards sample b and sample b + batch/2 have the same x
+ * and timestep and differ only in their context rows (p_sample_ddim's x_in = cat([x] * 2), :5347-5349):
+ * the layers ahead of the first cross-attention then run on one half of the batch.  Ignored for hybrid
+ * (concat) inputs and odd batches.  Default 0. */
+int sdmi_unet_set_cfg_duplicate(sdmi_unet* u, int enable);
 /* Bytes of device memory currently held (weights + caches + workspace). */
 int64_t sdmi_unet_device_bytes(const sdmi_unet* u);
 /* 1: replay the forward as a captured HIP graph when shapes and pointers repeat (default), 0: eager. */

@@ -47,6 +47,7 @@ SIGNATURES = {
     "sdmi_unet_device_bytes": (c_int64, [c_void_p]),
     "sdmi_unet_set_graph_mode": (c_int, [c_void_p, c_int]),
     "sdmi_unet_set_uniform_timesteps": (c_int, [c_void_p, c_int]),
+    "sdmi_unet_set_cfg_duplicate": (c_int, [c_void_p, c_int]),
     "sdmi_unet_destroy": (None, [c_void_p]),
     "sdmi_ddim_step": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float,
                                c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p]),

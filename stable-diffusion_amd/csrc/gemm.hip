@@ -56,6 +56,7 @@ struct GemmParams {
   float* partial;
   int tiles_m, tiles_n;
   const char* zero;   // 256 zero bytes (halo / out-of-range rows read these)
+  int dup_rows;       // > 0: rows are stored a second time dup_rows further down
   int wide_store;     // large-tile kernel: 16-bit output written through the LDS strips
   int dbg;   // timing experiments only: bit0 = activation loads hit the zero page, bit1 = weight loads
 };
@@ -109,6 +110,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
   typedef T Tx4 __attribute__((ext_vector_type(4)));
   Tx4 ov = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
   *reinterpret_cast<Tx4*>(o) = ov;
+  if (p.dup_rows > 0) *reinterpret_cast<Tx4*>(o + (size_t)p.dup_rows * p.ldo) = ov;
 }
 
 // GEGLU: value and gate sums for the same 4 output columns.
@@ -244,8 +246,10 @@ __device__ __forceinline__ void store_wave_tile_lds(const GemmParams& p, f32x4 (
       Tout o;
 #pragma unroll
       for (int e = 0; e < EPC; ++e) o[e] = from_f32<OutT>(v[e]);
-      if (lane + 64 * k < TOTAL && m < p.M && (!(p.dbg & 32) || v[0] == 12345.678f))
+      if (lane + 64 * k < TOTAL && m < p.M && (!(p.dbg & 32) || v[0] == 12345.678f)) {
         *reinterpret_cast<Tout*>(out + (size_t)m * ldo + n_out + c_col[k]) = o;
+        if (p.dup_rows > 0) *reinterpret_cast<Tout*>(out + (size_t)(m + p.dup_rows) * ldo + n_out + c_col[k]) = o;
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -673,7 +677,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
     float* strip = reinterpret_cast<float*>(smem + wid * (16 * (16 * NFW + 4) * 4));
     static_assert(8 * 16 * (16 * NFW + 4) * 4 <= S::LDS_BYTES, "strips do not fit");
     if (p.partial) {
-      pe.resid = nullptr;                                            // applied by the reduction pass
+      pe.resid = nullptr; pe.dup_rows = 0;                           // applied by the reduction pass
       store_wave_tile_lds<T, float, NFW, false>(pe, acc, strip, p.partial + (size_t)blockIdx.y * p.M * p.N, p.N,
                                                 m_wave, n_wave, lane);
     } else if (p.out_f32) {
@@ -844,6 +848,9 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   p.B = a.B; p.Hin = a.Hin; p.Win = a.Win; p.Ho = a.Ho; p.Wo = a.Wo;
   p.taps = a.taps; p.stride = a.stride; p.up = a.up;
   p.M = a.B * a.Ho * a.Wo; p.N = a.N; p.K = a.taps * (p.c0 + p.c1); p.geglu = a.geglu;
+  p.dup_rows = a.dup_rows;
+  SDMI_REQUIRE(a.dup_rows == 0 || (a.dup_rows >= p.M && !a.geglu && !a.out_f32),
+               "conv_gemm: dup_rows must skip past the computed rows and excludes GEGLU / fp32 outputs");
   SDMI_REQUIRE(a.a0 && a.w && a.out, "conv_gemm: null pointer");
   SDMI_REQUIRE(a.taps == 1 || a.taps == 9, "conv_gemm: taps must be 1 or 9 (got %d)", a.taps);
   SDMI_REQUIRE(a.stride == 1 || a.stride == 2, "conv_gemm: stride must be 1 or 2");

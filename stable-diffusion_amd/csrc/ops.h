@@ -43,6 +43,9 @@ struct ConvGemmArgs {
   // conv_gemm() launches the reduction+epilogue kernel itself.
   int splits = 1;
   float* partial = nullptr;
+  // > 0: every output row m is also stored at row m + dup_rows of `out` (two samples that are known to
+  // be identical so far are computed once); not with GEGLU or fp32 outputs
+  int dup_rows = 0;
 };
 int conv_gemm(const ConvGemmArgs& a, hipStream_t stream);
 int conv_gemm_init();   // one-time kernel attribute setup; call outside stream capture

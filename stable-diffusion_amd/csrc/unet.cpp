@@ -95,12 +95,17 @@ struct sdmi_unet {
   // every sample of a forward carries the same timestep (promise of the caller): embedding MLP on one row
   int uniform_t = 0;
   int emb_rows = 0;
+  // samples b and b + B/2 of a forward have identical x, timestep and concat inputs and differ only in
+  // their context (classifier-free guidance pairs; promise of the caller): everything up to the first
+  // cross-attention is computed for one half and stored twice
+  int cfg_dup = 0;
+  int next_dup_rows = 0;        // consumed by the next gemm()
 
   // graph replay
   int graph_mode = 1;
   struct GraphKey {
     const void* x; const void* c0; const void* c1; const void* t; void* out;
-    int n_concat, cc0, cc1, B, H, W, uniform_t; hipStream_t stream;
+    int n_concat, cc0, cc1, B, H, W, uniform_t, cfg_dup; hipStream_t stream;
     bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
   };
   GraphKey gkey; bool ghave = false;
@@ -397,6 +402,7 @@ struct sdmi_unet {
     g.bias = bias_override ? bias_override : pc.bias; g.rowadd = rowadd; g.ldra = ldra; g.resid = resid; g.ldr = ldr;
     g.B = B; g.Hin = Hin; g.Win = Win; g.Ho = Ho; g.Wo = Wo; g.taps = pc.taps; g.stride = stride; g.up = up;
     g.N = pc.cout; g.geglu = geglu; g.dtype = dtype;
+    g.dup_rows = next_dup_rows; next_dup_rows = 0;
     const int M = B * Ho * Wo, K = pc.taps * (c0 + (a1 ? c1 : 0));
     g.splits = conv_gemm_pick_splits(M, pc.cout, K, dtype, geglu != 0);
     if (g.splits > 1) g.partial = (float*)ws.get("splitk", (size_t)g.splits * M * pc.cout * 4);
@@ -420,15 +426,18 @@ struct sdmi_unet {
     return groupnorm(a, s);
   }
 
+  // dup: compute samples 0..B/2-1 only and store the block's output for both halves
   int run_res(const ResW& r, const Tensor& x0, const Tensor* x1, Tensor* y, const std::string& out_role,
-              const float* emb_all, const Fwd& f) {
-    const int B = f.B, H = x0.H, W = x0.W;
+              const float* emb_all, const Fwd& f, bool dup = false) {
+    const int H = x0.H, W = x0.W;
+    const int B = dup ? f.B / 2 : f.B;
+    const int dup_rows = dup ? B * H * W : 0;
     const int cin = x0.C + (x1 ? x1->C : 0);
     SDMI_REQUIRE(cin == r.cin, "%s: got %d input channels, expected %d", r.prefix.c_str(), cin, r.cin);
     SDMI_REQUIRE(r.has_skip || !x1, "%s: identity skip over a concatenated input is not supported", r.prefix.c_str());
     void* nrm = ws.get("nrm", act_bytes(B, H, W, cin > r.cout ? cin : r.cout));
     void* t1 = ws.get("t1", act_bytes(B, H, W, r.cout));
-    y->p = ws.get(out_role, act_bytes(B, H, W, r.cout)); y->H = H; y->W = W; y->C = r.cout;
+    y->p = ws.get(out_role, act_bytes(f.B, H, W, r.cout)); y->H = H; y->W = W; y->C = r.cout;
     SDMI_TRY(gn(x0, x1, B, r.gn1_g, r.gn1_b, 1e-5f, 1, nrm, f.s));
     SDMI_TRY(gemm(nrm, cin, nullptr, 0, r.conv1, t1, r.cout, B, H, W, H, W, 1, 0, emb_all + r.emb_off,
                   emb_rows == 1 && B > 1 ? -1 : emb_total,
@@ -438,9 +447,11 @@ struct sdmi_unet {
     if (r.has_skip) {
       SDMI_TRY(gemm(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, r.skip, y->p, r.cout, B, H, W, H, W, 1, 0,
                     nullptr, 0, nullptr, 0, 0, nullptr, f.s));
+      next_dup_rows = dup_rows;
       SDMI_TRY(gemm(nrm, r.cout, nullptr, 0, r.conv2, y->p, r.cout, B, H, W, H, W, 1, 0, nullptr, 0, y->p, r.cout, 0,
                     nullptr, f.s));
     } else {
+      next_dup_rows = dup_rows;
       SDMI_TRY(gemm(nrm, r.cout, nullptr, 0, r.conv2, y->p, r.cout, B, H, W, H, W, 1, 0, nullptr, 0, x0.p, x0.C, 0,
                     nullptr, f.s));
     }
@@ -463,8 +474,11 @@ struct sdmi_unet {
     return layernorm(x, out, g, b, rows, d, 1e-5f, dtype, s);
   }
 
-  int run_st(const STW& st, const Tensor& x, Tensor* y, const std::string& out_role, const Fwd& f) {
+  // dup: the two halves of the batch enter identical; the first block's self-attention, its output
+  // projection and the cross-attention query projection run on one half and are stored twice
+  int run_st(const STW& st, const Tensor& x, Tensor* y, const std::string& out_role, const Fwd& f, bool dup = false) {
     const int B = f.B, H = x.H, W = x.W, N = H * W, rows = B * N, d = st.inner;
+    const int Bh = dup ? B / 2 : B, rows_h = Bh * N;
     const size_t esz = sdmi_dtype_size(dtype);
     SDMI_REQUIRE(x.C == st.ch, "%s: got %d channels, expected %d", st.prefix.c_str(), x.C, st.ch);
     void* nrm = ws.get("nrm", act_bytes(B, H, W, st.ch));
@@ -474,18 +488,24 @@ struct sdmi_unet {
     void* att = ws.get("att", (size_t)rows * d * esz);
     void* ffm = ws.get("ffm", (size_t)rows * 4 * d * esz);
     y->p = ws.get(out_role, act_bytes(B, H, W, st.ch)); y->H = H; y->W = W; y->C = st.ch;
-    SDMI_TRY(gn(x, nullptr, B, st.gn_g, st.gn_b, 1e-6f, 0, nrm, f.s));
-    SDMI_TRY(linear(nrm, st.ch, st.proj_in, xt, d, rows, nullptr, 0, 0, f.s));
+    SDMI_TRY(gn(x, nullptr, Bh, st.gn_g, st.gn_b, 1e-6f, 0, nrm, f.s));
+    SDMI_TRY(linear(nrm, st.ch, st.proj_in, xt, d, rows_h, nullptr, 0, 0, f.s));
+    bool first = true;
     for (const auto& tb : st.blocks) {
+      const bool half = dup && first;             // later blocks see diverged halves
+      const int bq = half ? Bh : B, rq = half ? rows_h : rows;
+      first = false;
       // self-attention
-      SDMI_TRY(ln(xt, lnb, tb.ln_g[0], tb.ln_b[0], rows, d, f.s));
-      SDMI_TRY(linear(lnb, d, tb.qkv, qkv, 3 * d, rows, nullptr, 0, 0, f.s));
+      SDMI_TRY(ln(xt, lnb, tb.ln_g[0], tb.ln_b[0], rq, d, f.s));
+      SDMI_TRY(linear(lnb, d, tb.qkv, qkv, 3 * d, rq, nullptr, 0, 0, f.s));
       SDMI_TRY(attn(qkv, 3 * d, (char*)qkv + (size_t)d * esz, 3 * d, (char*)qkv + (size_t)2 * d * esz, 3 * d, att, d,
-                    B, st.heads, N, N, st.dh, f.s));
-      SDMI_TRY(linear(att, d, tb.out1, xt, d, rows, xt, d, 0, f.s));
+                    bq, st.heads, N, N, st.dh, f.s));
+      if (half) next_dup_rows = rows_h;
+      SDMI_TRY(linear(att, d, tb.out1, xt, d, rq, xt, d, 0, f.s));
       // cross-attention against the cached context projections
-      SDMI_TRY(ln(xt, lnb, tb.ln_g[1], tb.ln_b[1], rows, d, f.s));
-      SDMI_TRY(linear(lnb, d, tb.q2, qkv, d, rows, nullptr, 0, 0, f.s));
+      SDMI_TRY(ln(xt, lnb, tb.ln_g[1], tb.ln_b[1], rq, d, f.s));
+      if (half) next_dup_rows = rows_h;
+      SDMI_TRY(linear(lnb, d, tb.q2, qkv, d, rq, nullptr, 0, 0, f.s));
       SDMI_TRY(attn(qkv, d, tb.kv_cache, 2 * d, (char*)tb.kv_cache + (size_t)d * esz, 2 * d, att, d, B, st.heads, N,
                     ctx_ntok, st.dh, f.s));
       SDMI_TRY(linear(att, d, tb.out2, xt, d, rows, xt, d, 0, f.s));
@@ -498,8 +518,10 @@ struct sdmi_unet {
     return SDMI_OK;
   }
 
+  // dup_block: this block is [ResBlock, SpatialTransformer] directly behind the first convolution and
+  // the batch halves are identical on entry
   int run_layers(const std::vector<Layer>& layers, Tensor h, const Tensor* skip, Tensor* out,
-                 const std::string& block_role, const float* emb_all, const Fwd& f) {
+                 const std::string& block_role, const float* emb_all, const Fwd& f, bool dup_block = false) {
     for (size_t li = 0; li < layers.size(); ++li) {
       const bool last = li + 1 == layers.size();
       const std::string role = last ? block_role : (li % 2 == 0 ? std::string("tmp_a") : std::string("tmp_b"));
@@ -520,10 +542,10 @@ struct sdmi_unet {
           break;
         }
         case L_RES:
-          SDMI_TRY(run_res(res[l.idx], h, li == 0 ? skip : nullptr, &y, role, emb_all, f));
+          SDMI_TRY(run_res(res[l.idx], h, li == 0 ? skip : nullptr, &y, role, emb_all, f, dup_block && li == 0));
           break;
         case L_ST:
-          SDMI_TRY(run_st(sts[l.idx], h, &y, role, f));
+          SDMI_TRY(run_st(sts[l.idx], h, &y, role, f, dup_block && li == 1));
           break;
         case L_DOWN: {
           const SimpleConv& c = downs[l.idx];
@@ -565,7 +587,10 @@ struct sdmi_unet {
     Tensor h;
     for (size_t i = 0; i < input_blocks.size(); ++i) {
       Tensor y;
-      SDMI_TRY(run_layers(input_blocks[i], h, nullptr, &y, "in" + std::to_string(i), emb_all, f));
+      const std::vector<Layer>& L = input_blocks[i];
+      const bool dup_block = cfg_dup && i == 1 && f.B % 2 == 0 && f.n_concat == 0 && L.size() == 2 &&
+                             L[0].kind == L_RES && L[1].kind == L_ST && !res[L[0].idx].has_skip;
+      SDMI_TRY(run_layers(L, h, nullptr, &y, "in" + std::to_string(i), emb_all, f, dup_block));
       hs.push_back(y);
       h = y;
     }
@@ -610,7 +635,7 @@ struct sdmi_unet {
     memset(&k, 0, sizeof(k));
     k.x = f.x; k.c0 = f.n_concat > 0 ? f.concat[0] : nullptr; k.c1 = f.n_concat > 1 ? f.concat[1] : nullptr;
     k.t = f.t; k.out = f.out; k.n_concat = f.n_concat; k.cc0 = f.cc[0]; k.cc1 = f.cc[1];
-    k.B = f.B; k.H = f.H; k.W = f.W; k.uniform_t = uniform_t; k.stream = nullptr;
+    k.B = f.B; k.H = f.H; k.W = f.W; k.uniform_t = uniform_t; k.cfg_dup = cfg_dup; k.stream = nullptr;
     if (!(ghave && k == gkey)) {
       drop_graph();
       // the caller's stream may be the legacy default stream, which cannot be captured: record the
@@ -702,6 +727,12 @@ int64_t sdmi_unet_device_bytes(const sdmi_unet* u) { return u ? (int64_t)u->mem.
 int sdmi_unet_set_uniform_timesteps(sdmi_unet* u, int enable) {
   SDMI_REQUIRE(u, "set_uniform_timesteps: null handle");
   u->uniform_t = enable ? 1 : 0;
+  return SDMI_OK;
+}
+
+int sdmi_unet_set_cfg_duplicate(sdmi_unet* u, int enable) {
+  SDMI_REQUIRE(u, "set_cfg_duplicate: null handle");
+  u->cfg_dup = enable ? 1 : 0;
   return SDMI_OK;
 }
 

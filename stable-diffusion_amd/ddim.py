@@ -193,10 +193,12 @@ class DDIMSampler(object):
             # run its time-embedding MLP on a single row
             unet = s.model.model.diffusion_model
             unet.set_uniform_timesteps(True)
+            unet.set_cfg_duplicate(self.doubled)       # x_in = cat([x] * 2): halves differ only in context
             try:
                 s.model.apply_model(self.x_in, self.t_in, cond, out=self.eps)
             finally:
                 unet.set_uniform_timesteps(False)
+                unet.set_cfg_duplicate(False)
             a_t, a_prev, sigma_t, sqrt_1m = s._scalars(index, use_original_steps)
             noise = None
             if sigma_t != 0.:

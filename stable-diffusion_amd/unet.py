@@ -135,6 +135,10 @@ class UNetModel:
         """Promise that all samples of the following forwards share one timestep (sampler loops do)."""
         check(_lib.lib().sdmi_unet_set_uniform_timesteps(self._h, 1 if enable else 0), "set_uniform_timesteps")
 
+    def set_cfg_duplicate(self, enable: bool):
+        """Promise that samples b and b + B/2 of the following forwards share x and t (CFG pairs)."""
+        check(_lib.lib().sdmi_unet_set_cfg_duplicate(self._h, 1 if enable else 0), "set_cfg_duplicate")
+
     def set_graph_mode(self, enable: bool):
         check(_lib.lib().sdmi_unet_set_graph_mode(self._h, 1 if enable else 0), "set_graph_mode")
 

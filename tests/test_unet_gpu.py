@@ -89,6 +89,28 @@ def test_uniform_timestep_promise_changes_nothing(dt):
     net.set_graph_mode(True)
 
 
+@pytest.mark.parametrize("dt", ["fp32", "fp16"])
+def test_cfg_duplicate_promise(dt):
+    """x_in = cat([x] * 2) with different contexts: computing the layers ahead of the first
+    cross-attention once must match the full-batch forward (sums regroup, so not bit for bit)."""
+    net = device_unet(4, dt)
+    g = golden("g3_unet_c2")
+    x1 = g["x"][:1].cuda()
+    x, t, ctx = torch.cat([x1, x1]), g["t"].cuda(), g["ctx"].float().cuda()
+    for graph in (False, True):
+        net.set_graph_mode(graph)
+        ref = net(x, t, context=ctx).clone()
+        net.set_cfg_duplicate(True)
+        try:
+            out = net(x, t, context=ctx).clone()
+        finally:
+            net.set_cfg_duplicate(False)
+        err = max_rel_err(out.cpu(), ref.cpu())
+        assert err < (2e-5 if dt == "fp32" else 3e-3), (dt, graph, err)
+        assert not torch.equal(out[0], out[1])           # the halves did diverge at the cross-attention
+    net.set_graph_mode(True)
+
+
 def test_errors_are_loud():
     net = device_unet(4, "fp16")
     g = golden("g3_unet_c1")

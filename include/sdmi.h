@@ -139,6 +139,26 @@ int sdmi_vae_decoder_finalize(sdmi_vae_decoder* v, void* stream);
 int sdmi_vae_decoder_forward(sdmi_vae_decoder* v, const void* z, float z_scale, void* out, int batch,
                              int h, int w, void* stream);
 void sdmi_vae_decoder_destroy(sdmi_vae_decoder* v);
+/* VAE encoder (AutoencoderKL.encode :1410-1414, Encoder.forward :393-420, DownsampleEncoder :88-99).
+ * Same cfg struct: out_ch is the number of image channels; the weights are `encoder.*` and `quant_conv.*`.
+ * x: fp32 NCHW [batch][out_ch][h][w] (h, w divisible by 2^(n_ch_mult-1)); moments: fp32 NCHW
+ * [batch][2 embed_dim][h/8][w/8] = (mean | logvar) of the posterior, the argument of
+ * DiagonalGaussianDistribution :624. */
+typedef struct sdmi_vae_encoder sdmi_vae_encoder;
+int sdmi_vae_encoder_create(const sdmi_vae_cfg* cfg, sdmi_vae_encoder** out);
+int sdmi_vae_encoder_num_weights(const sdmi_vae_encoder* v);
+int sdmi_vae_encoder_weight_info(const sdmi_vae_encoder* v, int index, const char** key, int64_t* shape4, int* ndim);
+int sdmi_vae_encoder_set_weight(sdmi_vae_encoder* v, const char* key, const void* dev_ptr,
+                                const int64_t* shape, int ndim, int dtype, void* stream);
+int sdmi_vae_encoder_finalize(sdmi_vae_encoder* v, void* stream);
+int sdmi_vae_encoder_forward(sdmi_vae_encoder* v, const void* x, void* moments, int batch, int h, int w,
+                             void* stream);
+void sdmi_vae_encoder_destroy(sdmi_vae_encoder* v);
+/* z = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise)   (DiagonalGaussianDistribution.sample :636-638,
+ * get_first_stage_encoding :4264-4271 with scale = scale_factor); noise NULL: z = scale * mean (mode :656).
+ * moments fp32 [batch][2 channels][hw], noise / z fp32 [batch][channels][hw]. */
+int sdmi_gaussian_sample(const void* moments, const void* noise, float scale, void* z, int batch, int channels,
+                         int hw, void* stream);
 /* out = clamp((x + 1) / 2, 0, 1)   (txt2img.py:307) */
 int sdmi_to_image(const void* x, void* out, int64_t n, void* stream);
 
@@ -160,12 +180,13 @@ int sdmi_pack_weight(const float* w, void* out, int out_ch, int in_ch, int taps,
 int sdmi_pack_geglu(const float* w, const float* b, void* wout, float* bout, int inner, int in_ch, int dtype,
                     void* stream);
 /* nn.Conv2d 3x3 pad 1 / 1x1 / nn.Linear as implicit GEMM (Downsample :3095 stride 2, Upsample
- * :3062-3064 up = 1, skip-concat :3545 via a1).  w from sdmi_pack_weight.  splits >= 1; partial =
+ * :3062-3064 up = 1, skip-concat :3545 via a1; pad_lo = 1, or 0 for DownsampleEncoder :96-99's
+ * F.pad (0,1,0,1) + stride-2 conv).  w from sdmi_pack_weight.  splits >= 1; partial =
  * fp32 scratch of splits*M*N floats when splits > 1. */
 int sdmi_conv2d(const void* a0, int c0, const void* a1, int c1, const void* w, const float* bias,
                 const float* rowadd, const void* resid, int ldr, void* out, int ldo, int batch, int hin,
-                int win, int taps, int stride, int up, int n_out, int geglu, int splits, void* partial,
-                int dtype, void* stream);
+                int win, int taps, int stride, int pad_lo, int up, int n_out, int geglu, int splits,
+                void* partial, int dtype, void* stream);
 /* Split count the UNet executor uses for an (m x k) * (k x n) problem of this dtype (1 = no split);
  * callers that want the executor's schedule size `partial` from it.  No counterpart in the reference. */
 int sdmi_conv2d_splits(int m, int n, int k, int dtype);

@@ -289,12 +289,28 @@ def g9b(sdm):
     save("g9_inpaint", x_T=x_T, mask=mask, masked=masked, uc=uc.half(), c=c.half(), z=z)
 
 
+@torch.no_grad()
+def g10(sdm, model):
+    """VAE encode: AutoencoderKL.encode -> DiagonalGaussianDistribution, and the scaled posterior sample."""
+    est = S.vae_encoder_structure(S.sd_v1_ddconfig(), 4)
+    missing, unexpected = model.first_stage_model.load_state_dict(
+        synth.synth_state_dict(S.vae_encoder_param_shapes(est), WSEED), strict=False)
+    assert not unexpected, unexpected
+    x = synth.uniform(41, "g10.image", (1, 3, 128, 128), -1.0, 1.0)
+    noise = synth.normal(42, "g10.noise", (1, 4, 16, 16))
+    post = model.encode_first_stage(x)
+    assert isinstance(post, sdm.DiagonalGaussianDistribution)
+    z = model.scale_factor * (post.mean + post.std * noise)        # sample() :636 with the noise made explicit
+    save("g10_vae_encode", x=x, noise=noise, moments=post.parameters, mean=post.mean, logvar=post.logvar,
+         std=post.std, z=z, z_mode=model.scale_factor * post.mode())
+
+
 def main(argv):
-    names = argv or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g9b", "g7"]
+    names = argv or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g9b", "g7", "g10"]
     torch.manual_seed(0)
     sdm = import_reference()
     model = None
-    need_model = {"g4", "g5", "g6", "g7", "g8", "g9"} & set(names)
+    need_model = {"g4", "g5", "g6", "g7", "g8", "g9", "g10"} & set(names)
     for n in names:
         t0 = time.time()
         if n == "g1":
@@ -308,7 +324,7 @@ def main(argv):
         else:
             if model is None and need_model:
                 model = ref_latent_diffusion(sdm)
-            {"g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9}[n](sdm, model)
+            {"g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10}[n](sdm, model)
         print(f"[{n}] done in {time.time() - t0:.1f}s", flush=True)
 
 

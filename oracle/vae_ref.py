@@ -1,4 +1,4 @@
-"""fp32 torch-CPU restatement of the reference VAE decode path (TEST INFRASTRUCTURE ONLY).
+"""fp32 torch-CPU restatement of the reference VAE decode and encode paths (TEST INFRASTRUCTURE ONLY).
 
 State-dict keys are relative to ``first_stage_model.``; file cited = /root/reference/stable_diffusion.py.
 """
@@ -74,6 +74,40 @@ def decode(sd, st, z):
 def decode_first_stage(sd, st, z, scale_factor=0.18215):
     """LatentDiffusion.decode_first_stage :4300, :4346."""
     return decode(sd, st, 1. / scale_factor * z)
+
+
+@torch.no_grad()
+def encoder_forward(sd, st, x):
+    """Encoder.forward :393-420 (no attention in the down levels for the SD config)."""
+    h = _conv(x, sd, "encoder.conv_in")
+    for l in st.layers:
+        if isinstance(l, _S.VaeResSpec):
+            h = resnet_block(h, sd, l)
+        elif isinstance(l, _S.VaeAttnSpec):
+            h = attn_block(h, sd, l)
+        elif isinstance(l, _S.VaeDownSpec):
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)         # DownsampleEncoder :94-96
+            h = F.conv2d(h, sd[l.prefix + ".weight"], sd[l.prefix + ".bias"], stride=2, padding=0)
+    h = swish(_gn(h, sd, "encoder.norm_out"))
+    return _conv(h, sd, "encoder.conv_out")
+
+
+@torch.no_grad()
+def encode(sd, st, x):
+    """AutoencoderKL.encode :1410-1414 -> the moments tensor (mean | logvar) behind the posterior."""
+    return _conv(encoder_forward(sd, st, x), sd, "quant_conv", padding=0)
+
+
+def gaussian_sample(moments, noise):
+    """DiagonalGaussianDistribution :624-638: mean + exp(0.5 clamp(logvar, -30, 20)) * noise."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    logvar = torch.clamp(logvar, -30.0, 20.0)
+    return mean + torch.exp(0.5 * logvar) * noise
+
+
+def get_first_stage_encoding(moments, noise, scale_factor=0.18215):
+    """LatentDiffusion.get_first_stage_encoding :4264-4271 on a posterior given by its moments."""
+    return scale_factor * gaussian_sample(moments, noise)
 
 
 def to_image(x):

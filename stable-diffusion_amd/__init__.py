@@ -5,7 +5,8 @@ LatentDiffusion, DDIMSampler, AutoencoderKL) over hand-written gfx950 kernels in
 Importing the package needs neither the library nor a GPU; using a model does.
 """
 from .structure import (sd_v1_unet_config, sd_v1_ddconfig, sd_v1_model_params, unet_structure,
-                        unet_param_shapes, vae_decoder_structure, vae_decoder_param_shapes)
+                        unet_param_shapes, vae_decoder_structure, vae_decoder_param_shapes,
+                        vae_encoder_structure, vae_encoder_param_shapes)
 from . import synth
 
 
@@ -20,7 +21,7 @@ def __getattr__(name):
     if name in ("DDIMSampler", "make_ddim_timesteps", "make_ddim_sampling_parameters"):
         from . import ddim
         return getattr(ddim, name)
-    if name == "AutoencoderKL":
+    if name in ("AutoencoderKL", "DiagonalGaussianDistribution"):
         from . import autoencoder
-        return autoencoder.AutoencoderKL
+        return getattr(autoencoder, name)
     raise AttributeError(name)

@@ -59,6 +59,14 @@ SIGNATURES = {
     "sdmi_vae_decoder_finalize": (c_int, [c_void_p, c_void_p]),
     "sdmi_vae_decoder_forward": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sdmi_vae_decoder_destroy": (None, [c_void_p]),
+    "sdmi_vae_encoder_create": (c_int, [P(VaeCfg), P(c_void_p)]),
+    "sdmi_vae_encoder_num_weights": (c_int, [c_void_p]),
+    "sdmi_vae_encoder_weight_info": (c_int, [c_void_p, c_int, P(c_char_p), P(c_int64), P(c_int)]),
+    "sdmi_vae_encoder_set_weight": (c_int, [c_void_p, c_char_p, c_void_p, P(c_int64), c_int, c_int, c_void_p]),
+    "sdmi_vae_encoder_finalize": (c_int, [c_void_p, c_void_p]),
+    "sdmi_vae_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sdmi_vae_encoder_destroy": (None, [c_void_p]),
+    "sdmi_gaussian_sample": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sdmi_to_image": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "sdmi_groupnorm_scratch_bytes": (c_int64, [c_int, c_int]),
     "sdmi_groupnorm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
@@ -67,7 +75,7 @@ SIGNATURES = {
     "sdmi_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sdmi_pack_geglu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sdmi_conv2d": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                            c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                            c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                             c_void_p, c_int, c_void_p]),
     "sdmi_conv2d_splits": (c_int, [c_int, c_int, c_int, c_int]),
     "sdmi_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,

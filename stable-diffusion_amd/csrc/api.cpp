@@ -165,15 +165,16 @@ int sdmi_pack_geglu(const float* w, const float* b, void* wout, float* bout, int
 
 int sdmi_conv2d(const void* a0, int c0, const void* a1, int c1, const void* w, const float* bias,
                 const float* rowadd, const void* resid, int ldr, void* out, int ldo, int batch, int hin, int win,
-                int taps, int stride, int up, int n_out, int geglu, int splits, void* partial, int dtype,
-                void* stream) {
+                int taps, int stride, int pad_lo, int up, int n_out, int geglu, int splits, void* partial,
+                int dtype, void* stream) {
   ConvGemmArgs a;
   a.a0 = a0; a.c0 = c0; a.a1 = a1; a.c1 = c1; a.w = w; a.bias = bias; a.rowadd = rowadd;
   a.resid = resid; a.ldr = ldr; a.out = out; a.ldo = ldo; a.B = batch; a.Hin = hin; a.Win = win;
   a.taps = taps; a.stride = stride; a.up = up; a.N = n_out; a.geglu = geglu; a.splits = splits;
   a.partial = (float*)partial; a.dtype = dtype;
   const int hup = up ? 2 * hin : hin, wup = up ? 2 * win : win;
-  if (taps == 9) { a.Ho = (hup + 2 - 3) / stride + 1; a.Wo = (wup + 2 - 3) / stride + 1; }
+  a.pad_lo = pad_lo;
+  if (taps == 9) { a.Ho = (hup + pad_lo + 1 - 3) / stride + 1; a.Wo = (wup + pad_lo + 1 - 3) / stride + 1; }
   else { a.Ho = (hup - 1) / stride + 1; a.Wo = (wup - 1) / stride + 1; }
   return conv_gemm(a, (hipStream_t)stream);
 }

@@ -201,6 +201,28 @@ __global__ void pointwise_nchw_kernel(const float* x, const float* w, const floa
   }
 }
 
+// ---- posterior sample (DiagonalGaussianDistribution :624-638, get_first_stage_encoding :4264-4271) ----
+// moments: NCHW fp32 [B][2C][HW] (mean | logvar); z = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise);
+// noise == nullptr gives the mode (mean).  Every product and sum is rounded separately, as the
+// reference's elementwise torch ops are.
+__global__ void gaussian_sample_kernel(const float* moments, const float* noise, float scale, float* z, int B, int C,
+                                       int HW) {
+#pragma clang fp contract(off)
+  const size_t total = (size_t)B * C * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / ((size_t)C * HW), r = i - b * (size_t)C * HW;
+    const float mean = moments[b * 2 * C * HW + r];
+    float v = mean;
+    if (noise) {
+      float lv = moments[b * 2 * C * HW + (size_t)C * HW + r];
+      lv = fminf(fmaxf(lv, -30.0f), 20.0f);
+      const float sd = expf(0.5f * lv);
+      v = mean + sd * noise[i];
+    }
+    z[i] = scale * v;
+  }
+}
+
 // ---- sampler -----------------------------------------------------------------------------------
 __global__ void ddim_step_kernel(const float* x, const float* eps, int cfg, float scale, float sqrt_at,
                                  float sqrt_aprev, float dir_coef, float sigma, float sqrt_1m_at,
@@ -398,8 +420,10 @@ static int out_conv_t(const void* x, const float* w, const float* bias, float* o
     hipLaunchKernelGGL((out_conv_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)x, w, bias, out, B, H, W, Cin);
   else if (Cout == 3)
     hipLaunchKernelGGL((out_conv_kernel<T, 3>), grid, dim3(256), 0, s, (const T*)x, w, bias, out, B, H, W, Cin);
+  else if (Cout == 8)
+    hipLaunchKernelGGL((out_conv_kernel<T, 8>), grid, dim3(256), 0, s, (const T*)x, w, bias, out, B, H, W, Cin);
   else {
-    sdmi_set_error("out_conv: Cout=%d unsupported (3 or 4)", Cout);
+    sdmi_set_error("out_conv: Cout=%d unsupported (3, 4 or 8)", Cout);
     return SDMI_EINVAL;
   }
   SDMI_CHECK_HIP(hipGetLastError());
@@ -411,6 +435,15 @@ int out_conv(const void* x, const float* w, const float* bias, float* out, int B
   SDMI_REQUIRE(x && w && bias && out, "out_conv: null pointer");
   SDMI_REQUIRE(Cin % 8 == 0, "out_conv: Cin must be a multiple of 8");
   SDMI_DISPATCH_DTYPE(dtype, T, return out_conv_t<T>(x, w, bias, out, B, H, W, Cin, Cout, s));
+  return SDMI_OK;
+}
+
+int gaussian_sample(const float* moments, const float* noise, float scale, float* z, int B, int C, int HW,
+                    hipStream_t s) {
+  SDMI_REQUIRE(moments && z && B > 0 && C > 0 && HW > 0, "gaussian_sample: bad arguments");
+  hipLaunchKernelGGL(gaussian_sample_kernel, dim3(grid_for((size_t)B * C * HW)), dim3(256), 0, s, moments, noise,
+                     scale, z, B, C, HW);
+  SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }
 

@@ -51,6 +51,7 @@ struct GemmParams {
   const char* w; char* out; int ldo;
   const float* bias; const float* rowadd; const char* resid; int ldr; int ldra; int out_f32;
   int B, Hin, Win, Ho, Wo, taps, stride, up;
+  int pad;            // zero rows/columns ahead of the image (3x3 taps): 1, or 0 for the VAE encoder's (0,1,0,1) padding
   int M, N, K, geglu;
   int nkt, kt_per_split;
   float* partial;
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(S::NTHREADS) void conv_gemm_kernel(GemmParams p) {
     pf_left = (src ? tiles_c1 : tiles_c0) - cseg;
     const char* base = src ? p.a1 : p.a0;
     const int cs = src ? p.c1 : p.c0;
-    const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
+    const int dy = p.taps == 9 ? tap / 3 - p.pad : 0, dx = p.taps == 9 ? tap - (tap / 3) * 3 - p.pad : 0;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       bool ok = a_ok[i];
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
     pf_left = (src ? tiles_c1 : tiles_c0) - cseg;
     const char* base = src ? p.a1 : p.a0;
     const int cs = src ? p.c1 : p.c0;
-    const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
+    const int dy = p.taps == 9 ? tap / 3 - p.pad : 0, dx = p.taps == 9 ? tap - (tap / 3) * 3 - p.pad : 0;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       bool ok = a_b[i] >= 0;
@@ -846,7 +847,7 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   p.bias = a.bias; p.rowadd = a.rowadd; p.resid = (const char*)a.resid; p.ldr = a.ldr;
   p.ldra = a.ldra > 0 ? a.ldra : (a.ldra < 0 ? 0 : a.N); p.out_f32 = a.out_f32;     // < 0: one row for every sample
   p.B = a.B; p.Hin = a.Hin; p.Win = a.Win; p.Ho = a.Ho; p.Wo = a.Wo;
-  p.taps = a.taps; p.stride = a.stride; p.up = a.up;
+  p.taps = a.taps; p.stride = a.stride; p.up = a.up; p.pad = a.taps == 9 ? a.pad_lo : 0;
   p.M = a.B * a.Ho * a.Wo; p.N = a.N; p.K = a.taps * (p.c0 + p.c1); p.geglu = a.geglu;
   p.dup_rows = a.dup_rows;
   SDMI_REQUIRE(a.dup_rows == 0 || (a.dup_rows >= p.M && !a.geglu && !a.out_f32),
@@ -863,8 +864,9 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
     SDMI_REQUIRE(a.Hin * a.Win == a.Ho * a.Wo, "conv_gemm: pointwise needs equal in/out sizes");
   else {
     const int Hup = a.up ? 2 * a.Hin : a.Hin, Wup = a.up ? 2 * a.Win : a.Win;
-    const int pad = a.taps == 9 ? 1 : 0, ks = a.taps == 9 ? 3 : 1;
-    SDMI_REQUIRE((Hup + 2 * pad - ks) / a.stride + 1 == a.Ho && (Wup + 2 * pad - ks) / a.stride + 1 == a.Wo,
+    const int pad2 = a.taps == 9 ? a.pad_lo + 1 : 0, ks = a.taps == 9 ? 3 : 1;      // trailing pad is always 1
+    SDMI_REQUIRE(a.pad_lo == 0 || a.pad_lo == 1, "conv_gemm: pad_lo must be 0 or 1");
+    SDMI_REQUIRE((Hup + pad2 - ks) / a.stride + 1 == a.Ho && (Wup + pad2 - ks) / a.stride + 1 == a.Wo,
                  "conv_gemm: output size %dx%d inconsistent with input %dx%d", a.Ho, a.Wo, a.Hin, a.Win);
   }
   p.nkt = p.K / BK;

@@ -35,6 +35,8 @@ struct ConvGemmArgs {
   int Ho = 1, Wo = 1;           // output spatial size
   int taps = 1;                 // 1 (pointwise / linear) or 9 (3x3, pad 1)
   int stride = 1;               // 1 or 2
+  int pad_lo = 1;               // 3x3: zero rows/columns ahead of the image (the trailing side always has 1);
+                                // 0 = F.pad(x, (0,1,0,1)) + conv(padding=0), the VAE encoder's downsample
   int up = 0;                   // 1: input is nearest-upsampled x2 on the fly
   int N = 0;                    // output channels (rows of Wp)
   int geglu = 0;                // 1: Wp rows interleave (value,gate) 16-row groups; out has N/2 columns
@@ -107,12 +109,16 @@ struct InConvArgs {
   int dtype = SDMI_F16;
 };
 int in_conv(const InConvArgs& a, hipStream_t s);
-// last convolution: NHWC dtype -> NCHW fp32, 3x3 pad 1, Cout <= 4
+// last convolution: NHWC dtype -> NCHW fp32, 3x3 pad 1, Cout in {3, 4, 8}
 int out_conv(const void* x, const float* w /*[Cout][9][Cin] fp32*/, const float* bias, float* out,
              int B, int H, int W, int Cin, int Cout, int dtype, hipStream_t s);
 // pointwise NCHW fp32 conv with tiny channel counts: out = W*(scale*x) + b  (post_quant_conv)
 int pointwise_nchw(const float* x, const float* w, const float* bias, float* out, int B, int Cin,
                    int Cout, int HW, float scale, hipStream_t s);
+
+// posterior sample of the VAE encoder: z = scale * (mean + exp(0.5 clamp(logvar)) * noise); noise null = mode
+int gaussian_sample(const float* moments, const float* noise, float scale, float* z, int B, int C, int HW,
+                    hipStream_t s);
 
 // fused classifier-free guidance + DDIM update (all fp32, NCHW or any layout: purely elementwise)
 //   e = e_u + scale (e_c - e_u);  pred_x0 = (x - sqrt_1m_at e)/sqrt(a_t);

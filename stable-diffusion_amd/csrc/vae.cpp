@@ -1,6 +1,10 @@
-// VAE decoder executor (AutoencoderKL.decode -> Decoder.forward, stable_diffusion.py:1416-1419,
-// :496-527): post_quant_conv -> conv_in -> mid (ResnetBlock, single-head attention, ResnetBlock) ->
-// up levels (ResnetBlocks + nearest-x2 + conv) -> GroupNorm + swish + conv_out.
+// VAE executors.
+// Decoder (AutoencoderKL.decode -> Decoder.forward, stable_diffusion.py:1416-1419, :496-527):
+// post_quant_conv -> conv_in -> mid (ResnetBlock, single-head attention, ResnetBlock) -> up levels
+// (ResnetBlocks + nearest-x2 + conv) -> GroupNorm + swish + conv_out.
+// Encoder (AutoencoderKL.encode -> Encoder.forward, :1410-1414, :393-420): conv_in -> down levels
+// (ResnetBlocks + DownsampleEncoder :88-99 = zero pad right/bottom, conv 3x3 stride 2) -> mid ->
+// GroupNorm + swish + conv_out -> quant_conv; the result is the (mean | logvar) moments tensor.
 //
 // Same kernels and NHWC layout as the UNet.  The mid-block attention (one head of width C over all
 // H*W tokens, :161-183) does not fit a register-resident flash tile, so it runs as two GEMMs
@@ -30,13 +34,14 @@ struct VAttnW {
   PackedConv q, k, v, proj;
 };
 struct VUpW { std::string prefix; int ch = 0; PackedConv conv; };
-enum VKind { V_RES, V_ATTN, V_UP };
+enum VKind { V_RES, V_ATTN, V_UP, V_DOWN };
 struct VLayer { VKind kind; int idx; };
 struct VT { void* p = nullptr; int H = 0, W = 0, C = 0; };
 
 }  // namespace
 
-struct sdmi_vae_decoder {
+struct VaeNet {
+  bool is_encoder = false;
   sdmi_vae_cfg cfg;
   int dtype = SDMI_F16;
   std::vector<WeightSpec> specs;
@@ -48,12 +53,12 @@ struct sdmi_vae_decoder {
   std::vector<VAttnW> attns;
   std::vector<VUpW> ups;
   std::vector<VLayer> layers;
-  int block_in = 0, final_ch = 0;
+  int block_in = 0, final_ch = 0, final_out = 0;
   float* inconv_w = nullptr; const float* inconv_b = nullptr;
   float* outconv_w = nullptr; const float* outconv_b = nullptr;
   const float *pq_w = nullptr, *pq_b = nullptr, *no_g = nullptr, *no_b = nullptr;
 
-  ~sdmi_vae_decoder() { mem.release_all(); }
+  ~VaeNet() { mem.release_all(); }
   void add_spec(const std::string& key, std::vector<int64_t> shape) { specs.push_back({key, std::move(shape)}); }
 
   void add_res(const std::string& p, int cin, int cout) {
@@ -78,7 +83,39 @@ struct sdmi_vae_decoder {
     layers.push_back({V_ATTN, (int)attns.size() - 1});
   }
 
+  int build_encoder_structure() {
+    const int nres = cfg.n_ch_mult;
+    add_spec("encoder.conv_in.weight", {cfg.ch, cfg.out_ch, 3, 3});
+    add_spec("encoder.conv_in.bias", {cfg.ch});
+    int bi = cfg.ch;
+    for (int lvl = 0; lvl < nres; ++lvl) {
+      const int bo = cfg.ch * cfg.ch_mult[lvl];
+      for (int i = 0; i < cfg.num_res_blocks; ++i) {
+        add_res("encoder.down." + std::to_string(lvl) + ".block." + std::to_string(i), bi, bo);
+        bi = bo;
+      }
+      if (lvl != nres - 1) {
+        VUpW u; u.prefix = "encoder.down." + std::to_string(lvl) + ".downsample.conv"; u.ch = bi;
+        add_spec(u.prefix + ".weight", {bi, bi, 3, 3}); add_spec(u.prefix + ".bias", {bi});
+        ups.push_back(u);
+        layers.push_back({V_DOWN, (int)ups.size() - 1});
+      }
+    }
+    add_res("encoder.mid.block_1", bi, bi);
+    add_attn("encoder.mid.attn_1", bi);
+    add_res("encoder.mid.block_2", bi, bi);
+    final_ch = bi;
+    block_in = cfg.ch;
+    add_spec("encoder.norm_out.weight", {bi}); add_spec("encoder.norm_out.bias", {bi});
+    add_spec("encoder.conv_out.weight", {2 * cfg.z_channels, bi, 3, 3});
+    add_spec("encoder.conv_out.bias", {2 * cfg.z_channels});
+    add_spec("quant_conv.weight", {2 * cfg.embed_dim, 2 * cfg.z_channels, 1, 1});
+    add_spec("quant_conv.bias", {2 * cfg.embed_dim});
+    return SDMI_OK;
+  }
+
   int build_structure() {
+    if (is_encoder) return build_encoder_structure();
     const int nres = cfg.n_ch_mult;
     block_in = cfg.ch * cfg.ch_mult[nres - 1];
     add_spec("post_quant_conv.weight", {cfg.z_channels, cfg.embed_dim, 1, 1});
@@ -122,16 +159,20 @@ struct sdmi_vae_decoder {
       drop.push_back(prefix + ".weight");
       return (int)SDMI_OK;
     };
-    pq_w = store.get("post_quant_conv.weight"); pq_b = store.get("post_quant_conv.bias");
+    const std::string half = is_encoder ? "encoder" : "decoder";
+    const std::string pq = is_encoder ? "quant_conv" : "post_quant_conv";
+    const int in_c = is_encoder ? cfg.out_ch : cfg.z_channels;           // channels of the NCHW fp32 input
+    final_out = is_encoder ? 2 * cfg.z_channels : cfg.out_ch;            // channels the last 3x3 conv writes
+    pq_w = store.get(pq + ".weight"); pq_b = store.get(pq + ".bias");
     void* p;
-    SDMI_TRY(mem.alloc(&p, (size_t)9 * cfg.z_channels * block_in * 4)); inconv_w = (float*)p;
-    SDMI_TRY(pack_inconv_weight(store.get("decoder.conv_in.weight"), inconv_w, block_in, cfg.z_channels, s));
-    inconv_b = store.get("decoder.conv_in.bias");
-    SDMI_TRY(mem.alloc(&p, (size_t)9 * final_ch * cfg.out_ch * 4)); outconv_w = (float*)p;
-    SDMI_TRY(pack_outconv_weight(store.get("decoder.conv_out.weight"), outconv_w, cfg.out_ch, final_ch, s));
-    outconv_b = store.get("decoder.conv_out.bias");
-    no_g = store.get("decoder.norm_out.weight"); no_b = store.get("decoder.norm_out.bias");
-    drop.push_back("decoder.conv_in.weight"); drop.push_back("decoder.conv_out.weight");
+    SDMI_TRY(mem.alloc(&p, (size_t)9 * in_c * block_in * 4)); inconv_w = (float*)p;
+    SDMI_TRY(pack_inconv_weight(store.get(half + ".conv_in.weight"), inconv_w, block_in, in_c, s));
+    inconv_b = store.get(half + ".conv_in.bias");
+    SDMI_TRY(mem.alloc(&p, (size_t)9 * final_ch * final_out * 4)); outconv_w = (float*)p;
+    SDMI_TRY(pack_outconv_weight(store.get(half + ".conv_out.weight"), outconv_w, final_out, final_ch, s));
+    outconv_b = store.get(half + ".conv_out.bias");
+    no_g = store.get(half + ".norm_out.weight"); no_b = store.get(half + ".norm_out.bias");
+    drop.push_back(half + ".conv_in.weight"); drop.push_back(half + ".conv_out.weight");
     for (auto& r : res) {
       const std::string& q = r.prefix;
       r.gn1_g = store.get(q + ".norm1.weight"); r.gn1_b = store.get(q + ".norm1.bias");
@@ -156,11 +197,13 @@ struct sdmi_vae_decoder {
 
   size_t act_bytes(int B, int H, int W, int C) const { return (size_t)B * H * W * C * sdmi_dtype_size(dtype); }
 
+  // up: 0 plain, 1 nearest x2 ahead of the conv, -1 the encoder's downsample (pad right/bottom, stride 2)
   int gemm(const void* a0, int c0, const void* w, const float* bias, int N, int taps, void* out, int ldo, int B,
            int Hin, int Win, int Ho, int Wo, int up, const void* resid, int ldr, int out_f32, hipStream_t s) {
     ConvGemmArgs g;
     g.a0 = a0; g.c0 = c0; g.w = w; g.out = out; g.ldo = ldo; g.bias = bias; g.resid = resid; g.ldr = ldr;
-    g.B = B; g.Hin = Hin; g.Win = Win; g.Ho = Ho; g.Wo = Wo; g.taps = taps; g.stride = 1; g.up = up; g.N = N;
+    g.B = B; g.Hin = Hin; g.Win = Win; g.Ho = Ho; g.Wo = Wo; g.taps = taps; g.N = N;
+    g.stride = up < 0 ? 2 : 1; g.pad_lo = up < 0 ? 0 : 1; g.up = up > 0 ? 1 : 0;
     g.dtype = dtype; g.out_f32 = out_f32;
     const int M = B * Ho * Wo;
     g.splits = conv_gemm_pick_splits(M, N, taps * c0, dtype);
@@ -228,14 +271,17 @@ struct sdmi_vae_decoder {
     return SDMI_OK;
   }
 
+  // decoder: z [B][z_channels][H][W] -> image [B][out_ch][8H][8W]; encoder: image [B][out_ch][H][W] ->
+  // moments [B][2 embed_dim][H/8][W/8]
   int run(const float* z, float z_scale, float* out, int B, int H, int W, hipStream_t s) {
-    float* zq = (float*)ws.get("zq", (size_t)B * cfg.z_channels * H * W * 4);
+    const int in_c = is_encoder ? cfg.out_ch : cfg.z_channels;
+    float* zq = is_encoder ? nullptr : (float*)ws.get("zq", (size_t)B * cfg.z_channels * H * W * 4);
     VT h;
     h.p = ws.get("h_a", act_bytes(B, H, W, block_in)); h.H = H; h.W = W; h.C = block_in;
     if (!ws.dry) {
-      SDMI_TRY(pointwise_nchw(z, pq_w, pq_b, zq, B, cfg.embed_dim, cfg.z_channels, H * W, z_scale, s));
+      if (!is_encoder) SDMI_TRY(pointwise_nchw(z, pq_w, pq_b, zq, B, cfg.embed_dim, cfg.z_channels, H * W, z_scale, s));
       InConvArgs a;
-      a.src[0] = zq; a.c[0] = cfg.z_channels; a.w = inconv_w; a.bias = inconv_b; a.out = h.p;
+      a.src[0] = is_encoder ? z : zq; a.c[0] = in_c; a.w = inconv_w; a.bias = inconv_b; a.out = h.p;
       a.B = B; a.H = H; a.W = W; a.Cout = block_in; a.dtype = dtype;
       SDMI_TRY(in_conv(a, s));
     }
@@ -247,24 +293,40 @@ struct sdmi_vae_decoder {
         SDMI_TRY(run_res(res[l.idx], h, &y, role, B, s));
       } else if (l.kind == V_ATTN) {
         SDMI_TRY(run_attn(attns[l.idx], h, &y, role, B, s));
-      } else {
+      } else if (l.kind == V_UP) {
         const VUpW& u = ups[l.idx];
         y.H = 2 * h.H; y.W = 2 * h.W; y.C = u.ch;
         y.p = ws.get(role, act_bytes(B, y.H, y.W, u.ch));
         SDMI_TRY(gemm(h.p, h.C, u.conv.w, u.conv.bias, u.ch, 9, y.p, u.ch, B, h.H, h.W, y.H, y.W, 1, nullptr, 0, 0, s));
+      } else {
+        const VUpW& u = ups[l.idx];
+        y.H = (h.H + 1 - 3) / 2 + 1; y.W = (h.W + 1 - 3) / 2 + 1; y.C = u.ch;
+        y.p = ws.get(role, act_bytes(B, y.H, y.W, u.ch));
+        SDMI_TRY(gemm(h.p, h.C, u.conv.w, u.conv.bias, u.ch, 9, y.p, u.ch, B, h.H, h.W, y.H, y.W, -1, nullptr, 0, 0, s));
       }
       h = y;
       flip ^= 1;
     }
     void* nrm = ws.get("nrm", act_bytes(B, h.H, h.W, h.C));
     SDMI_TRY(gn(h, B, no_g, no_b, 1, nrm, s));
-    if (!ws.dry) SDMI_TRY(out_conv(nrm, outconv_w, outconv_b, out, B, h.H, h.W, h.C, cfg.out_ch, dtype, s));
+    if (is_encoder) {
+      float* mom = (float*)ws.get("moments", (size_t)B * final_out * h.H * h.W * 4);
+      if (!ws.dry) {
+        SDMI_TRY(out_conv(nrm, outconv_w, outconv_b, mom, B, h.H, h.W, h.C, final_out, dtype, s));
+        SDMI_TRY(pointwise_nchw(mom, pq_w, pq_b, out, B, final_out, 2 * cfg.embed_dim, h.H * h.W, 1.0f, s));
+      }
+    } else if (!ws.dry) {
+      SDMI_TRY(out_conv(nrm, outconv_w, outconv_b, out, B, h.H, h.W, h.C, final_out, dtype, s));
+    }
     return SDMI_OK;
   }
 
   int forward(const float* z, float z_scale, float* out, int B, int H, int W, hipStream_t s) {
     if (!finalized) { sdmi_set_error("forward before finalize"); return SDMI_ESTATE; }
     SDMI_REQUIRE(z && out && B > 0 && H > 0 && W > 0, "vae forward: bad arguments");
+    if (is_encoder)
+      SDMI_REQUIRE(H % (1 << (cfg.n_ch_mult - 1)) == 0 && W % (1 << (cfg.n_ch_mult - 1)) == 0,
+                   "vae encoder: image size %dx%d must be divisible by %d", H, W, 1 << (cfg.n_ch_mult - 1));
     ws.dry = true; ws.need.clear();
     SDMI_TRY(run(z, z_scale, out, B, H, W, s));
     ws.dry = false;
@@ -276,15 +338,21 @@ struct sdmi_vae_decoder {
   }
 };
 
-extern "C" {
+struct sdmi_vae_decoder : VaeNet {};
+struct sdmi_vae_encoder : VaeNet {};
 
-int sdmi_vae_decoder_create(const sdmi_vae_cfg* cfg, sdmi_vae_decoder** out) {
-  SDMI_REQUIRE(cfg && out, "vae_decoder_create: null argument");
-  SDMI_REQUIRE(cfg->n_ch_mult > 0 && cfg->n_ch_mult <= 8, "vae_decoder_create: bad ch_mult length");
-  SDMI_REQUIRE(cfg->compute_dtype >= 0 && cfg->compute_dtype <= 2, "vae_decoder_create: bad compute_dtype");
+namespace {
+template <typename H>
+int create_vae(const sdmi_vae_cfg* cfg, H** out, bool encoder) {
+  SDMI_REQUIRE(cfg && out, "vae create: null argument");
+  SDMI_REQUIRE(cfg->n_ch_mult > 0 && cfg->n_ch_mult <= 8, "vae create: bad ch_mult length");
+  SDMI_REQUIRE(cfg->compute_dtype >= 0 && cfg->compute_dtype <= 2, "vae create: bad compute_dtype");
   SDMI_REQUIRE(cfg->ch % 64 == 0 && (cfg->out_ch == 3 || cfg->out_ch == 4) && cfg->z_channels <= 64,
-               "vae_decoder_create: ch must be a multiple of 64, out_ch 3 or 4");
-  std::unique_ptr<sdmi_vae_decoder> v(new sdmi_vae_decoder());
+               "vae create: ch must be a multiple of 64, image channels 3 or 4");
+  if (encoder)
+    SDMI_REQUIRE(2 * cfg->z_channels == 8, "vae encoder: z_channels must be 4 (the last conv writes 8 channels)");
+  std::unique_ptr<H> v(new H());
+  v->is_encoder = encoder;
   v->cfg = *cfg;
   v->dtype = cfg->compute_dtype;
   v->store.mem = &v->mem;
@@ -293,10 +361,7 @@ int sdmi_vae_decoder_create(const sdmi_vae_cfg* cfg, sdmi_vae_decoder** out) {
   *out = v.release();
   return SDMI_OK;
 }
-
-int sdmi_vae_decoder_num_weights(const sdmi_vae_decoder* v) { return v ? (int)v->specs.size() : 0; }
-
-int sdmi_vae_decoder_weight_info(const sdmi_vae_decoder* v, int index, const char** key, int64_t* shape4, int* ndim) {
+int vae_weight_info(const VaeNet* v, int index, const char** key, int64_t* shape4, int* ndim) {
   SDMI_REQUIRE(v && index >= 0 && index < (int)v->specs.size(), "weight_info: bad index");
   const WeightSpec& s = v->specs[index];
   if (key) *key = s.key.c_str();
@@ -305,12 +370,51 @@ int sdmi_vae_decoder_weight_info(const sdmi_vae_decoder* v, int index, const cha
     for (size_t i = 0; i < 4; ++i) shape4[i] = i < s.shape.size() ? s.shape[i] : 1;
   return SDMI_OK;
 }
-
-int sdmi_vae_decoder_set_weight(sdmi_vae_decoder* v, const char* key, const void* dev_ptr, const int64_t* shape,
-                                int ndim, int dtype, void* stream) {
+int vae_set_weight(VaeNet* v, const char* key, const void* dev_ptr, const int64_t* shape, int ndim, int dtype,
+                   void* stream) {
   SDMI_REQUIRE(v && key && dev_ptr && shape, "set_weight: null argument");
   if (v->finalized) { sdmi_set_error("set_weight after finalize"); return SDMI_ESTATE; }
   return v->store.set(v->specs, key, dev_ptr, shape, ndim, dtype, (hipStream_t)stream);
+}
+}  // namespace
+
+extern "C" {
+
+int sdmi_vae_decoder_create(const sdmi_vae_cfg* cfg, sdmi_vae_decoder** out) { return create_vae(cfg, out, false); }
+int sdmi_vae_encoder_create(const sdmi_vae_cfg* cfg, sdmi_vae_encoder** out) { return create_vae(cfg, out, true); }
+int sdmi_vae_encoder_num_weights(const sdmi_vae_encoder* v) { return v ? (int)v->specs.size() : 0; }
+int sdmi_vae_encoder_weight_info(const sdmi_vae_encoder* v, int index, const char** key, int64_t* shape4, int* ndim) {
+  return vae_weight_info(v, index, key, shape4, ndim);
+}
+int sdmi_vae_encoder_set_weight(sdmi_vae_encoder* v, const char* key, const void* dev_ptr, const int64_t* shape,
+                                int ndim, int dtype, void* stream) {
+  return vae_set_weight(v, key, dev_ptr, shape, ndim, dtype, stream);
+}
+int sdmi_vae_encoder_finalize(sdmi_vae_encoder* v, void* stream) {
+  SDMI_REQUIRE(v, "finalize: null handle");
+  return v->finalize((hipStream_t)stream);
+}
+int sdmi_vae_encoder_forward(sdmi_vae_encoder* v, const void* x, void* moments, int batch, int h, int w,
+                             void* stream) {
+  SDMI_REQUIRE(v, "forward: null handle");
+  return v->forward((const float*)x, 1.0f, (float*)moments, batch, h, w, (hipStream_t)stream);
+}
+void sdmi_vae_encoder_destroy(sdmi_vae_encoder* v) { delete v; }
+int sdmi_gaussian_sample(const void* moments, const void* noise, float scale, void* z, int batch, int channels,
+                         int hw, void* stream) {
+  return gaussian_sample((const float*)moments, (const float*)noise, scale, (float*)z, batch, channels, hw,
+                         (hipStream_t)stream);
+}
+
+int sdmi_vae_decoder_num_weights(const sdmi_vae_decoder* v) { return v ? (int)v->specs.size() : 0; }
+
+int sdmi_vae_decoder_weight_info(const sdmi_vae_decoder* v, int index, const char** key, int64_t* shape4, int* ndim) {
+  return vae_weight_info(v, index, key, shape4, ndim);
+}
+
+int sdmi_vae_decoder_set_weight(sdmi_vae_decoder* v, const char* key, const void* dev_ptr, const int64_t* shape,
+                                int ndim, int dtype, void* stream) {
+  return vae_set_weight(v, key, dev_ptr, shape, ndim, dtype, stream);
 }
 
 int sdmi_vae_decoder_finalize(sdmi_vae_decoder* v, void* stream) {

@@ -139,7 +139,11 @@ class LatentDiffusion:
     def encode_first_stage(self, x):
         return self.first_stage_model.encode(x)
 
-    def get_first_stage_encoding(self, encoder_posterior):
+    def get_first_stage_encoding(self, encoder_posterior, noise=None):
+        """scale_factor * posterior.sample() or scale_factor * tensor (:4264-4271); ``noise`` may be injected."""
+        from .autoencoder import DiagonalGaussianDistribution
+        if isinstance(encoder_posterior, DiagonalGaussianDistribution):
+            return encoder_posterior.sample(noise=noise, _scale=self.scale_factor)
         if isinstance(encoder_posterior, torch.Tensor):
             return self.scale_factor * encoder_posterior
         raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")

@@ -52,14 +52,14 @@ def pack_geglu(w_f32, b_f32, dtype):
 
 
 def conv2d(x, w_packed, bias=None, *, taps=9, stride=1, up=False, x1=None, rowadd=None, resid=None,
-           geglu=False, splits=1, n_out=None):
+           geglu=False, splits=1, n_out=None, pad_lo=1):
     """x: NHWC (B,H,W,C0) [+ x1 (B,H,W,C1)] -> NHWC (B,Ho,Wo,N) (N/2 with geglu)."""
     B, H, W, C0 = x.shape
     C1 = x1.shape[3] if x1 is not None else 0
     N = n_out if n_out is not None else w_packed.shape[0]
     Hup, Wup = (2 * H, 2 * W) if up else (H, W)
     if taps == 9:
-        Ho, Wo = (Hup + 2 - 3) // stride + 1, (Wup + 2 - 3) // stride + 1
+        Ho, Wo = (Hup + pad_lo + 1 - 3) // stride + 1, (Wup + pad_lo + 1 - 3) // stride + 1
     else:
         Ho, Wo = (Hup - 1) // stride + 1, (Wup - 1) // stride + 1
     No = N // 2 if geglu else N
@@ -71,7 +71,7 @@ def conv2d(x, w_packed, bias=None, *, taps=9, stride=1, up=False, x1=None, rowad
         partial = torch.empty((splits, B * Ho * Wo, N), dtype=torch.float32, device=x.device)
     check(_lib.lib().sdmi_conv2d(ptr(x), C0, ptr(x1), C1, ptr(w_packed), ptr(bias), ptr(rowadd), ptr(resid),
                                  resid.shape[-1] if resid is not None else 0, ptr(out), No, B, H, W, taps, stride,
-                                 1 if up else 0, N, 1 if geglu else 0, splits, ptr(partial), dtype_code(x.dtype),
+                                 pad_lo, 1 if up else 0, N, 1 if geglu else 0, splits, ptr(partial), dtype_code(x.dtype),
                                  stream_ptr()), "conv2d")
     return out
 

@@ -299,6 +299,12 @@ class VaeUpSpec:
 
 
 @dataclass
+class VaeDownSpec:
+    prefix: str      # "<...>.downsample.conv"
+    ch: int
+
+
+@dataclass
 class VaeDecoderStructure:
     z_channels: int
     embed_dim: int
@@ -346,14 +352,9 @@ def vae_decoder_structure(ddconfig: dict, embed_dim: int = 4) -> VaeDecoderStruc
     return st
 
 
-def vae_decoder_param_shapes(st: VaeDecoderStructure) -> "OrderedDict[str, Tuple[int, ...]]":
-    """Checkpoint keys (relative to ``first_stage_model.``) used by decode(), and their shapes."""
+def _vae_layer_shapes(layers) -> "OrderedDict[str, Tuple[int, ...]]":
     out = OrderedDict()
-    out["post_quant_conv.weight"] = (st.z_channels, st.embed_dim, 1, 1)
-    out["post_quant_conv.bias"] = (st.z_channels,)
-    out["decoder.conv_in.weight"] = (st.block_in, st.z_channels, 3, 3)
-    out["decoder.conv_in.bias"] = (st.block_in,)
-    for l in st.layers:
+    for l in layers:
         p = l.prefix
         if isinstance(l, VaeResSpec):
             out[f"{p}.norm1.weight"] = (l.cin,)
@@ -373,13 +374,84 @@ def vae_decoder_param_shapes(st: VaeDecoderStructure) -> "OrderedDict[str, Tuple
             for n in ("q", "k", "v", "proj_out"):
                 out[f"{p}.{n}.weight"] = (l.ch, l.ch, 1, 1)
                 out[f"{p}.{n}.bias"] = (l.ch,)
-        elif isinstance(l, VaeUpSpec):
+        elif isinstance(l, (VaeUpSpec, VaeDownSpec)):
             out[f"{p}.weight"] = (l.ch, l.ch, 3, 3)
             out[f"{p}.bias"] = (l.ch,)
+    return out
+
+
+def vae_decoder_param_shapes(st: VaeDecoderStructure) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Checkpoint keys (relative to ``first_stage_model.``) used by decode(), and their shapes."""
+    out = OrderedDict()
+    out["post_quant_conv.weight"] = (st.z_channels, st.embed_dim, 1, 1)
+    out["post_quant_conv.bias"] = (st.z_channels,)
+    out["decoder.conv_in.weight"] = (st.block_in, st.z_channels, 3, 3)
+    out["decoder.conv_in.bias"] = (st.block_in,)
+    out.update(_vae_layer_shapes(st.layers))
     out["decoder.norm_out.weight"] = (st.final_channels,)
     out["decoder.norm_out.bias"] = (st.final_channels,)
     out["decoder.conv_out.weight"] = (st.out_ch, st.final_channels, 3, 3)
     out["decoder.conv_out.bias"] = (st.out_ch,)
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# VAE encoder
+# --------------------------------------------------------------------------------------------
+@dataclass
+class VaeEncoderStructure:
+    z_channels: int
+    embed_dim: int
+    ch: int
+    in_channels: int
+    layers: list = field(default_factory=list)   # execution order after conv_in
+    final_channels: int = 0
+
+
+def vae_encoder_structure(ddconfig: dict, embed_dim: int = 4) -> VaeEncoderStructure:
+    """Execution-order description of Encoder (stable_diffusion.py:326-420)."""
+    ch_out = ddconfig["ch_out"]
+    ch_mult = tuple(ddconfig.get("ch_mult", (1, 2, 4, 8)))
+    nrb = ddconfig["num_res_blocks"]
+    if list(ddconfig.get("attn_resolutions", [])):
+        raise NotImplementedError("attention inside the encoder's down levels (attn_resolutions)")
+    if ddconfig.get("dropout", 0.0) != 0.0:
+        raise NotImplementedError("dropout != 0 (inference path only)")
+    if not ddconfig.get("resamp_with_conv", True):
+        raise NotImplementedError("resamp_with_conv=False")
+    if ddconfig.get("attn_type", "vanilla") != "vanilla" or ddconfig.get("use_linear_attn", False):
+        raise NotImplementedError("only vanilla attention in the encoder mid block")
+    if not ddconfig.get("double_z", True):
+        raise NotImplementedError("double_z=False")
+    st = VaeEncoderStructure(z_channels=ddconfig["z_channels"], embed_dim=embed_dim, ch=ch_out,
+                             in_channels=ddconfig.get("in_channels", ddconfig["out_ch"]))
+    block_in = ch_out
+    for i_level in range(len(ch_mult)):
+        block_out = ch_out * ch_mult[i_level]
+        for i_block in range(nrb):
+            st.layers.append(VaeResSpec(f"encoder.down.{i_level}.block.{i_block}", block_in, block_out))
+            block_in = block_out
+        if i_level != len(ch_mult) - 1:
+            st.layers.append(VaeDownSpec(f"encoder.down.{i_level}.downsample.conv", block_in))
+    st.layers.append(VaeResSpec("encoder.mid.block_1", block_in, block_in))
+    st.layers.append(VaeAttnSpec("encoder.mid.attn_1", block_in))
+    st.layers.append(VaeResSpec("encoder.mid.block_2", block_in, block_in))
+    st.final_channels = block_in
+    return st
+
+
+def vae_encoder_param_shapes(st: VaeEncoderStructure) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Checkpoint keys (relative to ``first_stage_model.``) used by encode(), and their shapes."""
+    out = OrderedDict()
+    out["encoder.conv_in.weight"] = (st.ch, st.in_channels, 3, 3)
+    out["encoder.conv_in.bias"] = (st.ch,)
+    out.update(_vae_layer_shapes(st.layers))
+    out["encoder.norm_out.weight"] = (st.final_channels,)
+    out["encoder.norm_out.bias"] = (st.final_channels,)
+    out["encoder.conv_out.weight"] = (2 * st.z_channels, st.final_channels, 3, 3)
+    out["encoder.conv_out.bias"] = (2 * st.z_channels,)
+    out["quant_conv.weight"] = (2 * st.embed_dim, 2 * st.z_channels, 1, 1)
+    out["quant_conv.bias"] = (2 * st.embed_dim,)
     return out
 
 

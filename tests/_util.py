@@ -64,7 +64,7 @@ def device_latent_diffusion(cin=4, conditioning_key="crossattn", dtype="fp16", s
         sd = {"model.diffusion_model." + k: synth.synth_tensor(seed, k, s, "cuda")
               for k, s in model.model.diffusion_model.state_dict_shapes().items()}
         sd.update({"first_stage_model." + k: synth.synth_tensor(seed, k, s, "cuda")
-                   for k, s in model.first_stage_model.state_dict_shapes().items()})
+                   for k, s in model.first_stage_model.state_dict_shapes(encoder=True).items()})
         model.load_state_dict(sd)
         _models[key] = model
     return _models[key]

@@ -153,6 +153,21 @@ def test_large_tiles_epilogues(ops, dt, monkeypatch):
         assert max_rel_err(y.float().cpu(), ref) < TOL[dt]
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", ["1", "2"])
+def test_conv2d_encoder_downsample(ops, dt, shape, monkeypatch):
+    """DownsampleEncoder: F.pad(x, (0,1,0,1)) then conv 3x3 stride 2 padding 0."""
+    monkeypatch.setenv("SDMI_GEMM_SHAPE", shape)
+    for (B, H, W, C, Cout) in ((2, 16, 16, 128, 256), (1, 12, 20, 64, 320)):
+        x = q(rnd("encdown.x", (B, C, H, W)), dt)
+        w = q(rnd("encdown.w", (Cout, C, 3, 3), -0.05, 0.05), dt)
+        b = rnd("encdown.b", (Cout,))
+        ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2, padding=0)
+        y = ops.conv2d(nhwc(x, dt), ops.pack_weight(w.cuda(), dt), b.cuda(), taps=9, stride=2, pad_lo=0)
+        assert tuple(y.shape) == (B, H // 2, W // 2, Cout)
+        assert max_rel_err(nchw(y), ref) < TOL[dt]
+
+
 def test_conv2d_planned_splits(ops):
     """splits=None asks the library for the executor's own split count."""
     x = q(rnd("plan.x", (2, 256, 8, 8)), "fp16")

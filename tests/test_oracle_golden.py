@@ -140,3 +140,16 @@ def test_g8_vae_decode():
     assert raw.shape == (1, 3, 256, 256)
     assert max_rel_err(raw, g["dec_raw"]) < 1e-5
     assert max_rel_err(vae_ref.decode_first_stage(sd, st, g["z"]), g["dec"]) < 1e-5
+
+
+def test_g10_vae_encode():
+    """Oracle encoder + posterior sample against the reference's AutoencoderKL.encode / posterior."""
+    g = golden("g10_vae_encode")
+    st = S.vae_encoder_structure(S.sd_v1_ddconfig(), 4)
+    sd = synth.synth_state_dict(S.vae_encoder_param_shapes(st), 0)
+    torch.set_num_threads(8)
+    mom = vae_ref.encode(sd, st, g["x"])
+    assert mom.shape == (1, 8, 16, 16)
+    assert max_rel_err(mom, g["moments"]) < 1e-5
+    assert max_rel_err(vae_ref.get_first_stage_encoding(g["moments"], g["noise"]), g["z"]) < 1e-6
+    assert torch.equal(vae_ref.gaussian_sample(g["moments"], g["noise"]), g["mean"] + g["std"] * g["noise"])

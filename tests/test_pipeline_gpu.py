@@ -38,6 +38,35 @@ def test_g8_vae_decode(dt):
     assert e1 < bar and e2 < bar
 
 
+@pytest.mark.parametrize("dt", ["fp32", "fp16", "bf16"])
+def test_g10_vae_encode(dt):
+    """AutoencoderKL.encode -> DiagonalGaussianDistribution -> get_first_stage_encoding (img2img/inpaint entry)."""
+    model = device_latent_diffusion(4, "crossattn", dt)
+    g = golden("g10_vae_encode")
+    post = model.encode_first_stage(g["x"].cuda())
+    torch.cuda.synchronize()
+    assert tuple(post.parameters.shape) == (1, 8, 16, 16)
+    # bf16 keeps 8 bits of mantissa through 25 conv layers: 2e-2 is the per-UNet-call bar, the encoder lands at it
+    bar = {"fp32": 1e-4, "fp16": 2e-2, "bf16": 4e-2}[dt]
+    e_mom = max_rel_err(post.parameters.cpu(), g["moments"])
+    z = model.get_first_stage_encoding(post, noise=g["noise"].cuda())
+    z_mode = post.mode(_scale=model.scale_factor)
+    e_z, e_m = max_rel_err(z.cpu(), g["z"]), max_rel_err(z_mode.cpu(), g["z_mode"])
+    print(f"vae encode {dt}: moments {e_mom:.3e} z {e_z:.3e} mode {e_m:.3e}")
+    assert e_mom < bar and e_z < bar and e_m < bar
+    assert max_rel_err(post.mean.cpu(), g["mean"]) < bar and max_rel_err(post.std.cpu(), g["std"]) < bar
+    # the fused sample kernel on the reference's own moments: only exp() may differ (by an ulp)
+    imp = importlib.import_module("stable-diffusion_amd.autoencoder")
+    ref_post = imp.DiagonalGaussianDistribution(g["moments"].cuda())
+    zz = ref_post.sample(noise=g["noise"].cuda(), _scale=model.scale_factor).cpu()
+    assert max_rel_err(zz, g["z"]) < 1e-6
+    assert torch.equal(ref_post.mode().cpu(), g["mean"])
+    # a second, non-square size against nothing but shape and finiteness (non-square, batch 2)
+    x2 = torch.rand(2, 3, 64, 128, device="cuda") * 2 - 1     # mid attention needs h*w/64 tokens in multiples of 64
+    p2 = model.encode_first_stage(x2)
+    assert tuple(p2.parameters.shape) == (2, 8, 8, 16) and bool(torch.isfinite(p2.parameters).all())
+
+
 @pytest.mark.parametrize("dt", ["fp32", "fp16"])
 def test_g6_c1_txt2img_end_to_end(dt):
     """C1: 256x256, 10 DDIM steps, batch 1, CFG 7.5, eta 0, + VAE decode + clamp."""

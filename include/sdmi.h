@@ -161,6 +161,13 @@ int sdmi_gaussian_sample(const void* moments, const void* noise, float scale, vo
                          int hw, void* stream);
 /* out = clamp((x + 1) / 2, 0, 1)   (txt2img.py:307) */
 int sdmi_to_image(const void* x, void* out, int64_t n, void* stream);
+/* out = uint8(255 * clamp((x + 1) / 2, 0, 1)), x fp32 NCHW [batch][channels][hw] -> out uint8 NHWC
+ * (txt2img.py:307, :316-317: the array handed to Image.fromarray) */
+int sdmi_to_image_u8(const void* x, void* out, int batch, int channels, int hw, void* stream);
+/* out = (1 - mask) * clamp((image + 1) / 2, 0, 1) + mask * predicted   (inpaint_with_text.py:286-291);
+ * image, predicted, out fp32 NCHW [batch][channels][hw], mask fp32 [batch][1][hw] */
+int sdmi_inpaint_composite(const void* image, const void* mask, const void* predicted, void* out, int batch,
+                           int channels, int hw, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-op entry points (unit parity tests; also usable on their own).  Activations are NHWC /

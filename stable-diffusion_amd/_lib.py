@@ -68,6 +68,8 @@ SIGNATURES = {
     "sdmi_vae_encoder_destroy": (None, [c_void_p]),
     "sdmi_gaussian_sample": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sdmi_to_image": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "sdmi_to_image_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sdmi_inpaint_composite": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sdmi_groupnorm_scratch_bytes": (c_int64, [c_int, c_int]),
     "sdmi_groupnorm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),

@@ -132,6 +132,14 @@ int sdmi_axpby(const void* a, const void* b, float ca, float cb, void* out, int6
   return axpby((const float*)a, (const float*)b, ca, cb, (float*)out, n, (hipStream_t)stream);
 }
 
+int sdmi_to_image_u8(const void* x, void* out, int batch, int channels, int hw, void* stream) {
+  return to_image_u8((const float*)x, (unsigned char*)out, batch, channels, hw, (hipStream_t)stream);
+}
+int sdmi_inpaint_composite(const void* image, const void* mask, const void* predicted, void* out, int batch,
+                           int channels, int hw, void* stream) {
+  return inpaint_composite((const float*)image, (const float*)mask, (const float*)predicted, (float*)out, batch,
+                           channels, hw, (hipStream_t)stream);
+}
 int sdmi_to_image(const void* x, void* out, int64_t n, void* stream) {
   return to_image((const float*)x, (float*)out, n, (hipStream_t)stream);
 }

@@ -479,6 +479,52 @@ int axpby(const float* a, const float* b, float ca, float cb, float* out, int64_
   return SDMI_OK;
 }
 
+// uint8 HWC image as the scripts save it (txt2img.py:307, :316-317): trunc(255 * clamp((x + 1) / 2, 0, 1)),
+// NCHW fp32 in, NHWC uint8 out; each product rounded to fp32 as numpy does.
+__global__ void to_image_u8_kernel(const float* x, unsigned char* out, int B, int C, int HW) {
+#pragma clang fp contract(off)
+  const size_t total = (size_t)B * HW * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t px = (i / C) % HW, b = i / ((size_t)C * HW);
+    float v = (x[(b * C + c) * HW + px] + 1.0f) / 2.0f;
+    v = fminf(fmaxf(v, 0.0f), 1.0f);
+    out[i] = (unsigned char)(255.0f * v);
+  }
+}
+
+// inpainted = (1 - mask) * clamp((image + 1) / 2, 0, 1) + mask * predicted  (inpaint_with_text.py:286-291);
+// image, predicted: NCHW fp32 [B][C][HW] (predicted already in [0,1]); mask: [B][1][HW]
+__global__ void inpaint_composite_kernel(const float* image, const float* mask, const float* pred, float* out, int B,
+                                         int C, int HW) {
+#pragma clang fp contract(off)
+  const size_t total = (size_t)B * C * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t px = i % HW, b = i / ((size_t)C * HW);
+    const float m = mask[b * HW + px];
+    float im = (image[i] + 1.0f) / 2.0f;
+    im = fminf(fmaxf(im, 0.0f), 1.0f);
+    out[i] = (1.0f - m) * im + m * pred[i];
+  }
+}
+
+int to_image_u8(const float* x, unsigned char* out, int B, int C, int HW, hipStream_t s) {
+  SDMI_REQUIRE(x && out && B > 0 && C > 0 && HW > 0, "to_image_u8: bad arguments");
+  hipLaunchKernelGGL(to_image_u8_kernel, dim3(grid_for((size_t)B * C * HW, 256, 4096)), dim3(256), 0, s, x, out, B, C,
+                     HW);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int inpaint_composite(const float* image, const float* mask, const float* pred, float* out, int B, int C, int HW,
+                      hipStream_t s) {
+  SDMI_REQUIRE(image && mask && pred && out && B > 0 && C > 0 && HW > 0, "inpaint_composite: bad arguments");
+  hipLaunchKernelGGL(inpaint_composite_kernel, dim3(grid_for((size_t)B * C * HW, 256, 4096)), dim3(256), 0, s, image,
+                     mask, pred, out, B, C, HW);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
 int to_image(const float* x, float* out, int64_t n, hipStream_t s) {
   SDMI_REQUIRE(x && out && n > 0, "to_image: bad arguments");
   hipLaunchKernelGGL(to_image_kernel, dim3(grid_for((size_t)n, 256, 4096)), dim3(256), 0, s, x, out, n);

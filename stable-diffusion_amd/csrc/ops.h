@@ -133,6 +133,9 @@ int axpby(const float* a, const float* b, float ca, float cb, float* out, int64_
 int softmax_rows(const float* s, void* p, int rows, int cols, float scale, int dtype, hipStream_t st);
 // out[i] = clamp((x[i]+1)/2, 0, 1)
 int to_image(const float* x, float* out, int64_t n, hipStream_t s);
+int to_image_u8(const float* x, unsigned char* out, int B, int C, int HW, hipStream_t s);
+int inpaint_composite(const float* image, const float* mask, const float* pred, float* out, int B, int C, int HW,
+                      hipStream_t s);
 
 // ---- weight packing (device side, run once at load) ---------------------------------------------
 // OIHW fp32 -> [O][tap][I] dtype (tap = ky*3+kx); also serves (O,I) linear weights with taps = 1

@@ -158,3 +158,23 @@ def to_image(x):
     out = torch.empty_like(x)
     check(_lib.lib().sdmi_to_image(ptr(x), ptr(out), x.numel(), stream_ptr()), "to_image")
     return out
+
+
+def to_image_u8(x):
+    """x NCHW fp32 in [-1, 1] -> uint8 NHWC, the array the reference hands to Image.fromarray."""
+    x = _f32(x)
+    b, c, h, w = x.shape
+    out = torch.empty((b, h, w, c), dtype=torch.uint8, device=x.device)
+    check(_lib.lib().sdmi_to_image_u8(ptr(x), ptr(out), b, c, h * w, stream_ptr()), "to_image_u8")
+    return out
+
+
+def inpaint_composite(image, mask, predicted):
+    """(1 - mask) * clamp((image + 1) / 2, 0, 1) + mask * predicted; mask (B,1,H,W)."""
+    image, mask, predicted = _f32(image), _f32(mask), _f32(predicted)
+    b, c, h, w = image.shape
+    assert tuple(mask.shape) == (b, 1, h, w) and predicted.shape == image.shape
+    out = torch.empty_like(image)
+    check(_lib.lib().sdmi_inpaint_composite(ptr(image), ptr(mask), ptr(predicted), ptr(out), b, c, h * w, stream_ptr()),
+          "inpaint_composite")
+    return out

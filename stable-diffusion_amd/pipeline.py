@@ -14,7 +14,8 @@ from . import synth
 from .structure import sd_v1_model_params
 
 
-def build_synthetic_model(in_channels=4, conditioning_key="crossattn", dtype="fp16", seed=0, device="cuda"):
+def build_synthetic_model(in_channels=4, conditioning_key="crossattn", dtype="fp16", seed=0, device="cuda",
+                          encoder=False):
     """LatentDiffusion with SD-v1-shaped weights from the deterministic synthesiser (no checkpoint
     exists offline).  Hash keys are the un-prefixed checkpoint names."""
     from .ddpm import LatentDiffusion
@@ -23,7 +24,7 @@ def build_synthetic_model(in_channels=4, conditioning_key="crossattn", dtype="fp
     sd = {"model.diffusion_model." + k: synth.synth_tensor(seed, k, s, device)
           for k, s in model.model.diffusion_model.state_dict_shapes().items()}
     sd.update({"first_stage_model." + k: synth.synth_tensor(seed, k, s, device)
-               for k, s in model.first_stage_model.state_dict_shapes().items()})
+               for k, s in model.first_stage_model.state_dict_shapes(encoder=encoder).items()})
     model.load_state_dict(sd)
     return model
 
@@ -55,6 +56,53 @@ def txt2img(model, x_T, uc, c, steps=50, scale=7.5, eta=0.0, sampler=None):
                           verbose=False)
     img = ops.to_image(model.decode_first_stage(z))
     return img, z
+
+
+@torch.no_grad()
+def img2img(model, init_image, uc, c, strength=0.75, steps=50, scale=5.0, eta=0.0, sampler=None, noise=None,
+            posterior_noise=None):
+    """The caller-side sequence of img2img.py:269-301 on the device: encode the image, noise it to
+    t_enc = int(strength * steps), denoise with CFG, decode.  Returns images in [0,1] and the latents."""
+    from . import ops
+    from .ddim import DDIMSampler
+    sampler = sampler or DDIMSampler(model)
+    b = init_image.shape[0]
+    init_latent = model.get_first_stage_encoding(model.encode_first_stage(init_image), noise=posterior_noise)
+    sampler.make_schedule(ddim_num_steps=steps, ddim_eta=eta, verbose=False)
+    assert 0. <= strength <= 1., 'can only work with strength in [0.0, 1.0]'
+    t_enc = int(strength * steps)
+    z_enc = sampler.stochastic_encode(init_latent, torch.tensor([t_enc] * b, device=init_latent.device), noise=noise)
+    cond = torch.cat([uc, c]) if scale != 1.0 else c
+    z = sampler.decode(z_enc, cond, t_enc, unconditional_guidance_scale=scale,
+                       unconditional_conditioning=True if scale != 1.0 else None)
+    return ops.to_image(model.decode_first_stage(z)), z
+
+
+@torch.no_grad()
+def inpaint(model, image, mask, uc, c, steps=50, scale=7.5, eta=0.0, sampler=None, noise=None, posterior_noise=None):
+    """inpaint_with_text.py:251-291 on the device (hybrid 9-channel UNet): image (B,3,H,W) in [-1,1], mask
+    (B,1,H,W) in {0,1} with 1 = repaint.  Returns the composited image in [0,1] and the latents."""
+    from . import ops
+    from .ddim import DDIMSampler
+    sampler = sampler or DDIMSampler(model)
+    b = image.shape[0]
+    dev = model.device
+    image, mask = image.to(dev, torch.float32), mask.to(dev, torch.float32)
+    masked_image = (1 - mask) * image                                           # make_batch :66
+    pn = posterior_noise if posterior_noise is not None else (None, None)
+    img_latent = model.get_first_stage_encoding(model.encode_first_stage(image), noise=pn[0])
+    masked_latent = model.get_first_stage_encoding(model.encode_first_stage(masked_image), noise=pn[1])
+    masked_latent = torch.cat([masked_latent] * 2)
+    img_mask = torch.nn.functional.interpolate(mask, size=img_latent.shape[-2:])
+    img_mask = torch.cat([img_mask] * 2)
+    sampler.make_schedule(ddim_num_steps=steps, ddim_eta=eta, verbose=False)
+    x_T = sampler.stochastic_encode(img_latent, torch.tensor([steps - 1], device=dev), noise=noise)
+    cond = {'c_concat': [[img_mask], [masked_latent]], 'c_crossattn': [torch.cat([uc, c])]}
+    z, _ = sampler.sample(S=steps, batch_size=b, shape=list(img_latent.shape[1:]), conditioning=cond, eta=eta,
+                          verbose=False, unconditional_guidance_scale=scale, unconditional_conditioning=True,
+                          x_T=x_T)
+    predicted = ops.to_image(model.decode_first_stage(z))
+    return ops.inpaint_composite(image, mask, predicted), z
 
 
 def shard(total, rank, world):

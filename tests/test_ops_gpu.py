@@ -300,6 +300,20 @@ def test_attention_ramping_scores(ops, d):
         assert max_rel_err(y.float().cpu(), ref) < TOL[dt] * 2
 
 
+def test_to_image_u8_and_inpaint_composite(ops):
+    """Bit-exact against the scripts' post-processing (txt2img.py:307,316-317; inpaint_with_text.py:286-291)."""
+    x = rnd("u8.x", (2, 3, 24, 40), -1.3, 1.3)
+    ref = torch.clamp((x + 1.0) / 2.0, min=0.0, max=1.0)
+    ref_u8 = (255. * ref.permute(0, 2, 3, 1).numpy()).astype(np.uint8)
+    y = ops.to_image_u8(x.cuda()).cpu().numpy()
+    assert y.shape == (2, 24, 40, 3) and np.array_equal(y, ref_u8)
+    mask = (rnd("u8.mask", (2, 1, 24, 40), 0., 1.) > 0.5).float()
+    pred = rnd("u8.pred", (2, 3, 24, 40), 0., 1.)
+    comp_ref = (1 - mask) * ref + mask * pred
+    comp = ops.inpaint_composite(x.cuda(), mask.cuda(), pred.cuda()).cpu()
+    assert torch.equal(comp, comp_ref)
+
+
 def test_timestep_embedding_g1(ops):
     g = golden("g1_timestep_embedding")
     y = ops.timestep_embedding(g["t"].cuda(), 320).cpu()

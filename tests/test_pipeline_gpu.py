@@ -117,6 +117,46 @@ def test_g7_c3_50_step_trajectory_psnr_fp16():
 
 
 @pytest.mark.parametrize("dt", ["fp32", "fp16"])
+def test_img2img_pipeline_against_oracle(dt):
+    """pipeline.img2img (img2img.py:269-301: encode -> posterior sample -> stochastic_encode -> decode() with
+    CFG -> decode_first_stage -> clamp) against the CPU oracle composing the same calls, 128x128, 4 steps."""
+    from oracle import unet_ref, sampler_ref, vae_ref
+    from _util import structure as S, synth
+    pipeline = importlib.import_module("stable-diffusion_amd.pipeline")
+    model = device_latent_diffusion(4, "crossattn", dt)
+    x = synth.uniform(51, "i2i.image", (1, 3, 128, 128), -1.0, 1.0)
+    pn = synth.normal(52, "i2i.posterior_noise", (1, 4, 16, 16))
+    noise = synth.normal(53, "i2i.noise", (1, 4, 16, 16))
+    uc = synth.normal(2, "uncond_ctx", (1, 77, 768)).half().float()
+    c = synth.normal(1, "cond_ctx.0", (1, 77, 768)).half().float()
+    steps, strength, scale = 4, 0.75, 5.0
+    img, z = pipeline.img2img(model, x.cuda(), uc.cuda(), c.cuda(), strength=strength, steps=steps, scale=scale,
+                              noise=noise.cuda(), posterior_noise=pn.cuda())
+    torch.cuda.synchronize()
+    # oracle
+    torch.set_num_threads(16)
+    est = S.vae_encoder_structure(S.sd_v1_ddconfig(), 4)
+    dst = S.vae_decoder_structure(S.sd_v1_ddconfig(), 4)
+    vsd = synth.synth_state_dict(S.vae_encoder_param_shapes(est), 0)
+    vsd.update(synth.synth_state_dict(S.vae_decoder_param_shapes(dst), 0))
+    ust = S.unet_structure(**S.sd_v1_unet_config(4))
+    usd = synth.synth_state_dict(S.unet_param_shapes(ust), 0)
+    z0 = vae_ref.get_first_stage_encoding(vae_ref.encode(vsd, est, x), pn)
+    ddpm = sampler_ref.ddpm_tables()
+    tab = sampler_ref.ddim_tables(ddpm["alphas_cumprod"], steps, 0.0)
+    t_enc = int(strength * steps)
+    z_enc = sampler_ref.stochastic_encode(z0, torch.tensor([t_enc]), tab, noise)
+    ctx = torch.cat([uc, c])
+    z_ref = sampler_ref.ddim_loop(lambda xi, ti: unet_ref.unet_forward(usd, ust, xi, ti, ctx), z_enc, steps, 0.0, scale,
+                                  ddpm, t_start=t_enc)
+    img_ref = vae_ref.to_image(vae_ref.decode_first_stage(vsd, dst, z_ref))
+    e_z, p = max_rel_err(z.cpu(), z_ref), psnr(img.cpu(), img_ref)
+    print(f"img2img pipeline {dt}: latent {e_z:.3e}, image PSNR {p:.1f} dB")
+    assert tuple(img.shape) == (1, 3, 128, 128)
+    assert e_z < (5e-4 if dt == "fp32" else 5e-2) and p > (60 if dt == "fp32" else 35)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "fp16"])
 def test_g9_img2img(dt):
     """stochastic_encode at strength 0.75 (t_enc = 37 of 50) then decode() with CFG 5.0."""
     model = device_latent_diffusion(4, "crossattn", dt)

@@ -107,6 +107,15 @@ void sdmi_unet_destroy(sdmi_unet* u);
 int sdmi_ddim_step(const void* x, const void* eps, int cfg, float scale, float a_t, float a_prev,
                    float sigma, float sqrt_one_minus_at, const void* noise, float temperature,
                    void* x_prev, void* pred_x0, int64_t n, void* stream);
+/* DDPM ancestral update, replaces LatentDiffusion.p_mean_variance :4672-4684 (predict_start_from_noise
+ * :3821-3825, the optional clamp, q_posterior :3839-3846) and the last line of p_sample :4710-4721:
+ *   x0     = sqrt_recip_acp * x - sqrt_recipm1_acp * eps          (clamped to [-1,1] if clip_denoised)
+ *   x_prev = mean_coef1 * x0 + mean_coef2 * x + noise_coef * (noise * temperature)
+ * The scalars are the schedule tables' entries at the step's timestep; noise_coef is
+ * (t != 0) * exp(0.5 * posterior_log_variance_clipped[t]).  noise may be NULL (t == 0); pred_x0 may be NULL. */
+int sdmi_ddpm_step(const void* x, const void* eps, float sqrt_recip_acp, float sqrt_recipm1_acp,
+                   int clip_denoised, float mean_coef1, float mean_coef2, float noise_coef, const void* noise,
+                   float temperature, void* x_prev, void* pred_x0, int64_t n, void* stream);
 /* out = ca * a + cb * b */
 int sdmi_axpby(const void* a, const void* b, float ca, float cb, void* out, int64_t n, void* stream);
 

@@ -206,6 +206,35 @@ def g5(sdm, model):
     save("g5_sampler_kat", **out)
 
 
+def g11(sdm, model):
+    """LatentDiffusion.p_sample (ancestral DDPM update) known answers with a stub eps model."""
+    b = 2
+    x = synth.normal(21, "g11.x", (b, 4, 16, 16))
+    eps = synth.normal(22, "g11.eps", (b, 4, 16, 16))
+    noise = synth.normal(23, "g11.noise", (b, 4, 16, 16))
+    out = {"x": x, "eps": eps, "noise": noise}
+    orig_apply, orig_noise = model.apply_model, sdm.noise_like
+    model.apply_model = lambda x_in, t_in, c, return_ids=False: eps
+    sdm.noise_like = lambda shape, device, repeat=False: noise
+    try:
+        for tv in (999, 500, 1, 0):
+            t = torch.full((b,), tv, dtype=torch.long)
+            for clip in (False, True):
+                for temp in (1.0, 0.7):
+                    xp, x0 = model.p_sample(x.clone(), None, t, clip_denoised=clip, return_x0=True, temperature=temp)
+                    out[f"t{tv}.clip{int(clip)}.temp{temp}.x_prev"] = xp
+                    out[f"t{tv}.clip{int(clip)}.temp{temp}.x0"] = x0
+        t = torch.tensor([7, 0], dtype=torch.long)
+        xp, x0 = model.p_sample(x.clone(), None, t, return_x0=True)
+        out["t7_0.x_prev"], out["t7_0.x0"] = xp, x0
+        for name in ("posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1",
+                     "posterior_mean_coef2", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod"):
+            out[f"tab.{name}"] = getattr(model, name).detach().clone()
+    finally:
+        model.apply_model, sdm.noise_like = orig_apply, orig_noise
+    save("g11_ddpm_kat", **out)
+
+
 def cfg_context(b):
     uc = f16r(synth.normal(2, "uncond_ctx", (b, 77, 768)))
     c = f16r(synth.normal(1, "cond_ctx", (b, 77, 768)))
@@ -306,11 +335,11 @@ def g10(sdm, model):
 
 
 def main(argv):
-    names = argv or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g9b", "g7", "g10"]
+    names = argv or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g9b", "g7", "g10", "g11"]
     torch.manual_seed(0)
     sdm = import_reference()
     model = None
-    need_model = {"g4", "g5", "g6", "g7", "g8", "g9", "g10"} & set(names)
+    need_model = {"g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"} & set(names)
     for n in names:
         t0 = time.time()
         if n == "g1":
@@ -324,7 +353,7 @@ def main(argv):
         else:
             if model is None and need_model:
                 model = ref_latent_diffusion(sdm)
-            {"g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10}[n](sdm, model)
+            {"g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}[n](sdm, model)
         print(f"[{n}] done in {time.time() - t0:.1f}s", flush=True)
 
 

@@ -23,6 +23,14 @@ def ddpm_tables(linear_start=0.00085, linear_end=0.012, n=1000):
         "alphas_cumprod_prev": f32(ac_prev),
         "sqrt_alphas_cumprod": f32(np.sqrt(ac)),
         "sqrt_one_minus_alphas_cumprod": f32(np.sqrt(1. - ac)),
+        "sqrt_recip_alphas_cumprod": f32(np.sqrt(1. / ac)),
+        "sqrt_recipm1_alphas_cumprod": f32(np.sqrt(1. / ac - 1)),
+        # v_posterior = 0 (:3782-3793)
+        "posterior_variance": f32(betas * (1. - ac_prev) / (1. - ac)),
+        "posterior_log_variance_clipped": f32(np.log(np.maximum(betas * (1. - ac_prev) / (1. - ac), 1e-20))),
+        "posterior_mean_coef1": f32(betas * np.sqrt(ac_prev) / (1. - ac)),
+        # the reference multiplies by (1 - alphas_cumprod) here (:3792-3793)
+        "posterior_mean_coef2": f32(np.sqrt(alphas) * (1. - ac_prev) * (1. - ac)),
     }
 
 
@@ -100,3 +108,19 @@ def ddim_loop(eps_model, x_T, S, eta, scale, tables_ddpm, noises=None, t_start=N
         img, _ = ddim_update(img, e_t, tab["alphas"][index], tab["alphas_prev"][index],
                              tab["sigmas"][index], tab["sqrt_one_minus_alphas"][index], noise)
     return img
+
+
+def ddpm_update(x, eps, t, tab, noise, clip_denoised=False, temperature=1.):
+    """LatentDiffusion.p_mean_variance :4672-4684 (predict_start_from_noise :3821-3825, q_posterior
+    :3839-3846) + p_sample :4710-4721 for the eps parameterization.  ``t`` is a (b,) long tensor;
+    returns (x_prev, x0)."""
+    shp = (x.shape[0],) + (1,) * (x.dim() - 1)
+    ext = lambda name: tab[name][t].reshape(shp)
+    x_recon = ext("sqrt_recip_alphas_cumprod") * x - ext("sqrt_recipm1_alphas_cumprod") * eps
+    if clip_denoised:
+        x_recon = x_recon.clamp(-1., 1.)
+    model_mean = ext("posterior_mean_coef1") * x_recon + ext("posterior_mean_coef2") * x
+    model_log_variance = ext("posterior_log_variance_clipped")
+    noise = noise * temperature
+    nonzero_mask = (1 - (t == 0).float()).reshape(shp)
+    return model_mean + nonzero_mask * (0.5 * model_log_variance).exp() * noise, x_recon

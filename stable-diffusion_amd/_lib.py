@@ -51,6 +51,8 @@ SIGNATURES = {
     "sdmi_unet_destroy": (None, [c_void_p]),
     "sdmi_ddim_step": (c_int, [c_void_p, c_void_p, c_int, c_float, c_float, c_float, c_float, c_float,
                                c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sdmi_ddpm_step": (c_int, [c_void_p, c_void_p, c_float, c_float, c_int, c_float, c_float, c_float, c_void_p,
+                               c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     "sdmi_axpby": (c_int, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
     "sdmi_vae_decoder_create": (c_int, [P(VaeCfg), P(c_void_p)]),
     "sdmi_vae_decoder_num_weights": (c_int, [c_void_p]),

@@ -128,6 +128,14 @@ int sdmi_ddim_step(const void* x, const void* eps, int cfg, float scale, float a
                    (const float*)noise, temperature, (float*)x_prev, (float*)pred_x0, n, (hipStream_t)stream);
 }
 
+int sdmi_ddpm_step(const void* x, const void* eps, float sqrt_recip_acp, float sqrt_recipm1_acp, int clip_denoised,
+                   float mean_coef1, float mean_coef2, float noise_coef, const void* noise, float temperature,
+                   void* x_prev, void* pred_x0, int64_t n, void* stream) {
+  return ddpm_step((const float*)x, (const float*)eps, sqrt_recip_acp, sqrt_recipm1_acp, clip_denoised, mean_coef1,
+                   mean_coef2, noise_coef, (const float*)noise, temperature, (float*)x_prev, (float*)pred_x0, n,
+                   (hipStream_t)stream);
+}
+
 int sdmi_axpby(const void* a, const void* b, float ca, float cb, void* out, int64_t n, void* stream) {
   return axpby((const float*)a, (const float*)b, ca, cb, (float*)out, n, (hipStream_t)stream);
 }

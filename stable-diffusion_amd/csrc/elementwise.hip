@@ -247,6 +247,23 @@ __global__ void ddim_step_kernel(const float* x, const float* eps, int cfg, floa
   }
 }
 
+// DDPM ancestral update: x0 from eps, the posterior mean of q(x_{t-1} | x_t, x0) and the noise term.
+// The per-timestep table entries arrive as scalars (the sampling loops use one t for the whole batch).
+__global__ void ddpm_step_kernel(const float* x, const float* eps, float c_recip, float c_recipm1, int clip,
+                                 float coef1, float coef2, float noise_coef, const float* noise,
+                                 float temperature, float* x_prev, float* pred_x0, int64_t n) {
+#pragma clang fp contract(off)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float xv = x[i];
+    float p0 = c_recip * xv - c_recipm1 * eps[i];
+    if (clip) p0 = fminf(fmaxf(p0, -1.0f), 1.0f);
+    const float mean = coef1 * p0 + coef2 * xv;
+    const float nz = noise ? noise_coef * (noise[i] * temperature) : 0.f;
+    if (pred_x0) pred_x0[i] = p0;
+    x_prev[i] = mean + nz;
+  }
+}
+
 __global__ void axpby_kernel(const float* a, const float* b, float ca, float cb, float* out, int64_t n) {
 #pragma clang fp contract(off)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -468,6 +485,16 @@ int ddim_step(const float* x, const float* eps, int cfg, float scale, float a_t,
   const float dir_coef = sqrtf(1.0f - a_prev - sigma * sigma);
   hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for((size_t)n, 256, 2048)), dim3(256), 0, s, x, eps, cfg, scale,
                      sqrt_at, sqrt_aprev, dir_coef, sigma, sqrt_1m_at, noise, temperature, x_prev, pred_x0, n);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int ddpm_step(const float* x, const float* eps, float c_recip, float c_recipm1, int clip, float coef1, float coef2,
+              float noise_coef, const float* noise, float temperature, float* x_prev, float* pred_x0, int64_t n,
+              hipStream_t s) {
+  SDMI_REQUIRE(x && eps && x_prev && n > 0, "ddpm_step: bad arguments");
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3(grid_for((size_t)n, 256, 2048)), dim3(256), 0, s, x, eps, c_recip,
+                     c_recipm1, clip, coef1, coef2, noise_coef, noise, temperature, x_prev, pred_x0, n);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

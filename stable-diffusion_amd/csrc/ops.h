@@ -128,6 +128,9 @@ int ddim_step(const float* x, const float* eps, int cfg, float scale, float a_t,
               float sigma, float sqrt_1m_at, const float* noise, float temperature, float* x_prev,
               float* pred_x0, int64_t n, hipStream_t s);
 // out = ca * a + cb * b   (stochastic_encode / q_sample with per-call scalars; fp32)
+int ddpm_step(const float* x, const float* eps, float c_recip, float c_recipm1, int clip, float coef1, float coef2,
+              float noise_coef, const float* noise, float temperature, float* x_prev, float* pred_x0, int64_t n,
+              hipStream_t s);
 int axpby(const float* a, const float* b, float ca, float cb, float* out, int64_t n, hipStream_t s);
 // row softmax over fp32 scores -> dtype probabilities (VAE mid-block attention, two-pass path)
 int softmax_rows(const float* s, void* p, int rows, int cols, float scale, int dtype, hipStream_t st);

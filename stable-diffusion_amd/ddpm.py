@@ -1,8 +1,9 @@
 """Host-side mirror of the reference's LatentDiffusion for the inference path.
 
 Keeps the names the sampler and the scripts use (stable_diffusion.py:3666-3895, :4044-4346,
-:4488-4589): ``apply_model``, ``decode_first_stage``, ``q_sample``, ``get_first_stage_encoding``,
-the schedule buffers and ``num_timesteps``.  The schedule is computed on the host in float64 exactly
+:4488-4589, :4660-4847): ``apply_model``, ``decode_first_stage``, ``q_sample``, ``get_first_stage_encoding``,
+the ancestral sampler (``p_mean_variance``, ``p_sample``, ``p_sample_loop``, ``sample``), the schedule
+buffers and ``num_timesteps``.  The schedule is computed on the host in float64 exactly
 as ``register_schedule`` does; everything that touches a latent runs on the GPU through libsdmi.
 """
 import functools
@@ -45,7 +46,8 @@ class LatentDiffusion:
     def __init__(self, first_stage_config, cond_stage_config=None, unet_config=None, linear_start=1e-4,
                  linear_end=2e-2, cosine_s=8e-3, timesteps=1000, beta_schedule="linear", scale_factor=1.0,
                  conditioning_key=None, concat_mode=True, parameterization="eps", v_posterior=0.,
-                 given_betas=None, compute_dtype="fp16", device=None, **ignored):
+                 given_betas=None, compute_dtype="fp16", device=None, log_every_t=100, image_size=256, channels=3,
+                 **ignored):
         assert parameterization in ["eps", "x0"], 'currently only supporting "eps" and "x0"'
         if conditioning_key is None:
             conditioning_key = 'concat' if concat_mode else 'crossattn'
@@ -54,6 +56,9 @@ class LatentDiffusion:
         self.parameterization = parameterization
         self.scale_factor = scale_factor
         self.v_posterior = v_posterior
+        self.log_every_t = log_every_t
+        self.image_size, self.channels = image_size, channels
+        self.clip_denoised = False      # LatentDiffusion overrides DDPM's default (:4089)
         self.device = torch.device(device if device is not None else "cuda")
         self.compute_dtype = compute_dtype
         self.model = DiffusionWrapper(unet_config, conditioning_key, compute_dtype=compute_dtype, device=self.device)
@@ -161,3 +166,136 @@ class LatentDiffusion:
             out[i] = ops.axpby(x_start[i], noise[i], float(self.sqrt_alphas_cumprod[t[i]]),
                                float(self.sqrt_one_minus_alphas_cumprod[t[i]]))
         return out
+
+    # ---- ancestral (DDPM) sampling -------------------------------------------------------------------
+    def _uniform_t(self, t, b):
+        t = torch.as_tensor(t).reshape(-1).cpu().long()
+        assert t.numel() == b, "one timestep per sample"
+        return t
+
+    def _ddpm_update(self, x, eps, t, clip_denoised, noise, temperature, want_x0):
+        """Fused x0 / posterior mean / noise update, one launch per distinct timestep in ``t``
+        (the sampling loops pass one value for the whole batch)."""
+        b = x.shape[0]
+        x_prev = torch.empty_like(x)
+        x0 = torch.empty_like(x) if want_x0 else None
+        # exp on the fp32 table entry, as the reference's tensor op does
+        sd = (0.5 * self.posterior_log_variance_clipped).exp()
+        lo = 0
+        while lo < b:
+            hi = lo + 1
+            while hi < b and t[hi] == t[lo]:
+                hi += 1
+            ti = int(t[lo])
+            mask = 0.0 if ti == 0 else 1.0
+            xp, p0 = ops.ddpm_step(x[lo:hi], eps[lo:hi], self.sqrt_recip_alphas_cumprod[ti],
+                                   self.sqrt_recipm1_alphas_cumprod[ti], self.posterior_mean_coef1[ti],
+                                   self.posterior_mean_coef2[ti], mask * float(sd[ti]),
+                                   noise=None if noise is None else noise[lo:hi], temperature=temperature,
+                                   clip_denoised=clip_denoised, want_pred_x0=want_x0, out=x_prev[lo:hi])
+            if want_x0:
+                x0[lo:hi] = p0
+            lo = hi
+        return x_prev, x0
+
+    def p_mean_variance(self, x, c, t, clip_denoised, return_codebook_ids=False, quantize_denoised=False,
+                        return_x0=False, score_corrector=None, corrector_kwargs=None):
+        """stable_diffusion.py:4660-4690: (model_mean, posterior_variance[t], posterior_log_variance[t][, x0])."""
+        if return_codebook_ids or quantize_denoised:
+            raise NotImplementedError("VQ first stage options are not on this path")
+        x = x.to(self.device, torch.float32).contiguous()
+        b = x.shape[0]
+        tt = self._uniform_t(t, b)
+        model_out = self.apply_model(x, torch.as_tensor(t).to(self.device), c)
+        if score_corrector is not None:
+            assert self.parameterization == "eps"
+            model_out = score_corrector.modify_score(self, model_out, x, t, c, **(corrector_kwargs or {}))
+        if self.parameterization != "eps":
+            raise NotImplementedError("the fused update implements the eps parameterization")
+        mean, x0 = self._ddpm_update(x, model_out.contiguous(), tt, clip_denoised, None, 1.0, return_x0)
+        shape = (b,) + (1,) * (x.dim() - 1)
+        var = self.posterior_variance[tt].reshape(shape).to(self.device)
+        logvar = self.posterior_log_variance_clipped[tt].reshape(shape).to(self.device)
+        return (mean, var, logvar, x0) if return_x0 else (mean, var, logvar)
+
+    @torch.no_grad()
+    def p_sample(self, x, c, t, clip_denoised=False, repeat_noise=False, return_codebook_ids=False,
+                 quantize_denoised=False, return_x0=False, temperature=1., noise_dropout=0., score_corrector=None,
+                 corrector_kwargs=None, noise=None):
+        """stable_diffusion.py:4693-4721.  One UNet call and one fused update kernel; ``noise`` may be
+        injected (the reference draws it with torch.randn)."""
+        if return_codebook_ids or quantize_denoised:
+            raise NotImplementedError("VQ first stage options are not on this path")
+        x = x.to(self.device, torch.float32).contiguous()
+        b = x.shape[0]
+        tt = self._uniform_t(t, b)
+        model_out = self.apply_model(x, torch.as_tensor(t).to(self.device), c)
+        if score_corrector is not None:
+            assert self.parameterization == "eps"
+            model_out = score_corrector.modify_score(self, model_out, x, t, c, **(corrector_kwargs or {}))
+        if self.parameterization != "eps":
+            raise NotImplementedError("the fused update implements the eps parameterization")
+        if noise is None:
+            if repeat_noise:
+                noise = torch.randn((1, *x.shape[1:]), device=self.device).repeat(b, *((1,) * (x.dim() - 1)))
+            else:
+                noise = torch.randn(x.shape, device=self.device)
+        noise = noise.to(self.device, torch.float32).contiguous()
+        if noise_dropout > 0.:
+            noise = torch.nn.functional.dropout(noise * temperature, p=noise_dropout)
+            temperature = 1.0
+        x_prev, x0 = self._ddpm_update(x, model_out.contiguous(), tt, clip_denoised, noise, temperature, return_x0)
+        return (x_prev, x0) if return_x0 else x_prev
+
+    @torch.no_grad()
+    def p_sample_loop(self, cond, shape, return_intermediates=False, x_T=None, verbose=True, callback=None,
+                      timesteps=None, quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None,
+                      log_every_t=None):
+        """stable_diffusion.py:4780-4829."""
+        if not log_every_t:
+            log_every_t = self.log_every_t
+        b = shape[0]
+        img = torch.randn(shape, device=self.device) if x_T is None else x_T.to(self.device, torch.float32)
+        intermediates = [img]
+        if timesteps is None:
+            timesteps = self.num_timesteps
+        if mask is not None:
+            assert x0 is not None
+            assert x0.shape[2:3] == mask.shape[2:3]
+        if start_T is not None:
+            timesteps = min(timesteps, start_T)
+        self.model.diffusion_model.set_uniform_timesteps(True)
+        try:
+            for i in reversed(range(0, timesteps)):
+                ts = torch.full((b,), i, device=self.device, dtype=torch.long)
+                img = self.p_sample(img, cond, ts, clip_denoised=self.clip_denoised,
+                                    quantize_denoised=quantize_denoised)
+                if mask is not None:
+                    img_orig = self.q_sample(x0, ts)
+                    img = img_orig * mask + (1. - mask) * img
+                if i % log_every_t == 0 or i == timesteps - 1:
+                    intermediates.append(img)
+                if callback:
+                    callback(i)
+                if img_callback:
+                    img_callback(img, i)
+        finally:
+            self.model.diffusion_model.set_uniform_timesteps(False)
+        if return_intermediates:
+            return img, intermediates
+        return img
+
+    @torch.no_grad()
+    def sample(self, cond, batch_size=16, return_intermediates=False, x_T=None, verbose=True, timesteps=None,
+               quantize_denoised=False, mask=None, x0=None, shape=None, **kwargs):
+        """stable_diffusion.py:4832-4847."""
+        if shape is None:
+            shape = (batch_size, self.channels, self.image_size, self.image_size)
+        if cond is not None:
+            if isinstance(cond, dict):
+                cond = {key: cond[key][:batch_size] if not isinstance(cond[key], list) else
+                        [x[:batch_size] for x in cond[key]] for key in cond}
+            else:
+                cond = [c[:batch_size] for c in cond] if isinstance(cond, list) else cond[:batch_size]
+        return self.p_sample_loop(cond, shape, return_intermediates=return_intermediates, x_T=x_T, verbose=verbose,
+                                  timesteps=timesteps, quantize_denoised=quantize_denoised, mask=mask, x0=x0)

@@ -146,6 +146,18 @@ def ddim_step(x, eps, cfg, scale, a_t, a_prev, sigma, sqrt_1m_at, noise=None, te
     return x_prev, pred
 
 
+def ddpm_step(x, eps, sqrt_recip_acp, sqrt_recipm1_acp, coef1, coef2, noise_coef, noise=None, temperature=1.0,
+              clip_denoised=False, want_pred_x0=True, out=None):
+    x, eps = _f32(x), _f32(eps)
+    x_prev = torch.empty_like(x) if out is None else out
+    pred = torch.empty_like(x) if want_pred_x0 else None
+    check(_lib.lib().sdmi_ddpm_step(ptr(x), ptr(eps), float(sqrt_recip_acp), float(sqrt_recipm1_acp),
+                                    1 if clip_denoised else 0, float(coef1), float(coef2), float(noise_coef),
+                                    ptr(noise), float(temperature), ptr(x_prev), ptr(pred), x.numel(),
+                                    stream_ptr()), "ddpm_step")
+    return x_prev, pred
+
+
 def axpby(a, b, ca, cb):
     a, b = _f32(a), _f32(b)
     out = torch.empty_like(a)

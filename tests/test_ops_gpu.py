@@ -356,6 +356,28 @@ def test_ddim_step_g5_bit_exact(ops):
         assert torch.equal(out.cpu(), g[f"stochastic_encode.t{tidx}"])
 
 
+def test_ddpm_step_g11_bit_exact(ops):
+    """The fused ancestral (DDPM) update reproduces LatentDiffusion.p_sample's fp32 results bit for bit."""
+    from oracle import sampler_ref
+    g = golden("g11_ddpm_kat")
+    tab = sampler_ref.ddpm_tables()
+    x, eps, noise = g["x"].cuda(), g["eps"].cuda(), g["noise"].cuda()
+    sd = (0.5 * tab["posterior_log_variance_clipped"]).exp()
+    for tv in (999, 500, 1, 0):
+        for clip in (False, True):
+            for temp in (1.0, 0.7):
+                xp, x0 = ops.ddpm_step(x, eps, tab["sqrt_recip_alphas_cumprod"][tv],
+                                       tab["sqrt_recipm1_alphas_cumprod"][tv], tab["posterior_mean_coef1"][tv],
+                                       tab["posterior_mean_coef2"][tv], (0.0 if tv == 0 else 1.0) * float(sd[tv]),
+                                       noise=noise, temperature=temp, clip_denoised=clip)
+                assert torch.equal(x0.cpu(), g[f"t{tv}.clip{int(clip)}.temp{temp}.x0"])
+                assert torch.equal(xp.cpu(), g[f"t{tv}.clip{int(clip)}.temp{temp}.x_prev"])
+    # noise pointer omitted at t == 0
+    xp, _ = ops.ddpm_step(x, eps, tab["sqrt_recip_alphas_cumprod"][0], tab["sqrt_recipm1_alphas_cumprod"][0],
+                          tab["posterior_mean_coef1"][0], tab["posterior_mean_coef2"][0], 0.0, want_pred_x0=False)
+    assert torch.equal(xp.cpu(), g["t0.clip0.temp1.0.x_prev"])
+
+
 # ---- golden block vectors (reference classes' own outputs) -------------------------------------------
 def _sd(shapes):
     return synth.synth_state_dict(shapes, 0)

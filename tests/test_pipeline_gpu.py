@@ -210,3 +210,45 @@ def test_eta_noise_path_and_p_sample_ddim_signature():
                                              tab["sigmas"][index], tab["sqrt_one_minus_alphas"][index], noise.cpu())
     assert torch.equal(pred_x0.cpu(), p0_ref)
     assert torch.equal(x_prev.cpu(), xp_ref)
+
+
+def test_ddpm_p_sample_and_loop_against_oracle():
+    """LatentDiffusion.p_sample / p_mean_variance / p_sample_loop mirrors: given the device UNet's eps, the
+    ancestral update equals the oracle's bit for bit (per-sample timesteps included); a short loop runs
+    with start_T and ends on the noise-free t == 0 step."""
+    from oracle import sampler_ref
+    model = device_latent_diffusion(4, "crossattn", "fp32")
+    tab = sampler_ref.ddpm_tables()
+    g3 = golden("g3_unet_c1")
+    x = torch.cat([g3["x"], g3["x"].flip(-1)]).cuda()
+    ctx = torch.cat([g3["ctx"].float()] * 2).cuda()
+    noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(9)).cuda()
+    for tv, clip in (([500, 500], False), ([3, 0], True)):
+        t = torch.tensor(tv, dtype=torch.long)
+        eps = model.apply_model(x, t.cuda(), ctx)
+        x_prev, x0 = model.p_sample(x, ctx, t, clip_denoised=clip, return_x0=True, noise=noise, temperature=0.9)
+        xp_ref, x0_ref = sampler_ref.ddpm_update(x.cpu(), eps.cpu(), t, tab, noise.cpu(), clip_denoised=clip,
+                                                 temperature=0.9)
+        assert torch.equal(x0.cpu(), x0_ref)
+        assert torch.equal(x_prev.cpu(), xp_ref)
+        mean, var, logvar, x0b = model.p_mean_variance(x, ctx, t, clip_denoised=clip, return_x0=True)
+        mean_ref, _ = sampler_ref.ddpm_update(x.cpu(), eps.cpu(), t, tab, torch.zeros_like(x_prev).cpu(),
+                                              clip_denoised=clip)
+        assert torch.equal(mean.cpu(), mean_ref) and torch.equal(x0b.cpu(), x0_ref)
+        assert torch.equal(var.cpu().flatten(), tab["posterior_variance"][t])
+        assert torch.equal(logvar.cpu().flatten(), tab["posterior_log_variance_clipped"][t])
+    # loop: 3 steps from t = 2, deterministic last step, against the oracle driven by the same eps model
+    torch.manual_seed(3)
+    seen = []
+    out, inter = model.p_sample_loop(ctx, tuple(x.shape), return_intermediates=True, x_T=x, start_T=3,
+                                     log_every_t=1, callback=seen.append, verbose=False)
+    assert seen == [2, 1, 0] and len(inter) == 4
+    torch.manual_seed(3)
+    img = x
+    for i in (2, 1, 0):
+        t = torch.full((2,), i, dtype=torch.long)
+        eps = model.apply_model(img, t.cuda(), ctx)
+        n = torch.randn(tuple(x.shape), device="cuda")
+        img, _ = sampler_ref.ddpm_update(img.cpu(), eps.cpu(), t, tab, n.cpu())
+        img = img.cuda()
+    assert max_rel_err(out.cpu(), img.cpu()) < 1e-5

@@ -4,8 +4,9 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch: batch-8 txt2img (UNet batch 16 with CFG) = 50 x
-[UNet forward + fused CFG/DDIM update] + VAE decode + clamp, fp16 compute, synthetic SD-v1-shaped
-weights, context tensors standing in for the CLIP output, inputs resident in HBM.  With N > 1 every
+[UNet forward + fused CFG/DDIM update] + VAE decode + clamp, preceded by the CLIP text transformer on the
+prompts' token ids; fp16 compute, synthetic SD-v1-shaped weights, synthetic token ids standing in for the
+tokenizer's output (--no-clip: context tensors instead), inputs resident in HBM.  With N > 1 every
 rank runs its own batch (weak scaling; samples are independent trajectories) and the decoded images
 are all-gathered over RCCL inside the timed region.  Rank 0 prints one JSON line.
 
@@ -49,6 +50,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-clip", action="store_true", help="feed (B,77,768) context tensors instead of running "
+                    "the text transformer on token ids inside the step")
     ap.add_argument("--no-c2", action="store_true", help="skip the batch-2 UNet timing (keeps the kernel "
                     "population of a profiled run identical to the roofline pass)")
     return ap.parse_args()
@@ -93,9 +96,10 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline(ddim_steps, size):
-    """Oracle on host cores: 2 UNet batch-2 forwards + 1 VAE decode, extrapolated to a full image."""
-    from oracle import unet_ref, vae_ref
+def cpu_baseline(ddim_steps, size, with_clip=True):
+    """Oracle on host cores: 2 UNet batch-2 forwards + 1 VAE decode (+ the text transformer on the empty and one
+    prompt), extrapolated to a full image."""
+    from oracle import unet_ref, vae_ref, clip_ref
     S = importlib.import_module("stable-diffusion_amd.structure")
     synth = importlib.import_module("stable-diffusion_amd.synth")
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1))
@@ -118,9 +122,20 @@ def cpu_baseline(ddim_steps, size):
     t0 = time.perf_counter()
     vae_ref.decode_first_stage(vsd, vst, x[:1])
     t_vae = time.perf_counter() - t0
-    per_image = ddim_steps * t_unet + t_vae
+    t_clip = 0.0
+    if with_clip:
+        del vsd
+        clip = importlib.import_module("stable-diffusion_amd.clip")
+        pipeline = importlib.import_module("stable-diffusion_amd.pipeline")
+        csd = synth.synth_state_dict(clip.clip_text_param_shapes(), 0)
+        ids = torch.cat(pipeline.synthetic_prompt_tokens(1, "cpu"))
+        t0 = time.perf_counter()
+        clip_ref.clip_text_forward(csd, ids)
+        t_clip = time.perf_counter() - t0
+    per_image = ddim_steps * t_unet + t_vae + t_clip
     return {"value": 1.0 / per_image, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{n_unet} UNet batch-2 forwards ({t_unet:.2f} s each) + 1 VAE decode ({t_vae:.2f} s) at "
+            "sample": f"{n_unet} UNet batch-2 forwards ({t_unet:.2f} s each) + 1 VAE decode ({t_vae:.2f} s) "
+                      f"+ text transformer on 2 token rows ({t_clip:.2f} s) at "
                       f"{size}x{size}, fp32 torch-CPU oracle, extrapolated to {ddim_steps} steps per image",
             "unet_it_per_s_batch2": 1.0 / t_unet}
 
@@ -144,14 +159,17 @@ def main():
     _lib = importlib.import_module("stable-diffusion_amd._lib")
     lib = _lib.lib()
 
-    model = pipeline.build_synthetic_model(4, "crossattn", args.dtype, device=dev)
+    model = pipeline.build_synthetic_model(4, "crossattn", args.dtype, device=dev, text_encoder=not args.no_clip)
     unet = model.model.diffusion_model
     if args.no_graph:
         unet.set_graph_mode(False)
     sampler = sdmi.DDIMSampler(model)
     B, h = args.batch, args.size // 8
     first = rank * B                                   # this rank's block of the global sample list
-    uc, c = pipeline.synthetic_conditioning(B, dev, first_sample=first)
+    if args.no_clip:
+        uc, c = pipeline.synthetic_conditioning(B, dev, first_sample=first)
+    else:
+        uc, c = pipeline.synthetic_prompt_tokens(B, dev, first_sample=first)
     x_T = pipeline.initial_latents(B, h, h, dev, first_sample=first)
 
     def step():
@@ -186,8 +204,10 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"txt2img {args.size}x{args.size}, {args.ddim_steps} DDIM steps, CFG {args.scale}, "
-                               f"batch {B}/GPU (UNet batch {2 * B}), UNet loop + fused CFG/DDIM update + VAE decode "
-                               f"+ clamp; SD-v1-shaped random weights; context tensors in place of CLIP",
+                               f"batch {B}/GPU (UNet batch {2 * B}), "
+                               + ("context tensors in place of CLIP" if args.no_clip else
+                                  "CLIP text transformer on synthetic token ids") +
+                               " + UNet loop + fused CFG/DDIM update + VAE decode + clamp; SD-v1-shaped random weights",
                    "global_batch": world * B, "latent": [4, h, h], "parallelism": f"replicas x{world} (sample shard)",
                    "graph_replay": not args.no_graph},
     }
@@ -257,7 +277,7 @@ def main():
             result[k + "_GBps"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else None
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.ddim_steps, args.size)
+        result["cpu_baseline"] = cpu_baseline(args.ddim_steps, args.size, with_clip=not args.no_clip)
 
     if world > 1:
         dist.barrier()

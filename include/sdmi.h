@@ -168,6 +168,38 @@ void sdmi_vae_encoder_destroy(sdmi_vae_encoder* v);
  * moments fp32 [batch][2 channels][hw], noise / z fp32 [batch][channels][hw]. */
 int sdmi_gaussian_sample(const void* moments, const void* noise, float scale, void* z, int batch, int channels,
                          int hw, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CLIP text transformer: replaces the arithmetic of FrozenCLIPEmbedder.forward :2569-2576
+ * (transformers' CLIPTextModel(input_ids).last_hidden_state; the tokenizer stays on the host).
+ * Weights use the checkpoint key names below `cond_stage_model.transformer.`:
+ * text_model.embeddings.{token,position}_embedding.weight, text_model.encoder.layers.N.
+ * {self_attn.{q,k,v,out}_proj, layer_norm1, mlp.fc1, mlp.fc2, layer_norm2}.{weight,bias},
+ * text_model.final_layer_norm.{weight,bias}.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sdmi_clip_text sdmi_clip_text;
+typedef struct sdmi_clip_cfg {
+  int vocab_size;     /* 49408 */
+  int hidden;         /* 768   */
+  int intermediate;   /* 3072  */
+  int layers;         /* 12    */
+  int heads;          /* 12    */
+  int max_positions;  /* 77    */
+  float ln_eps;       /* 1e-5  */
+  int compute_dtype;
+} sdmi_clip_cfg;
+int sdmi_clip_text_create(const sdmi_clip_cfg* cfg, sdmi_clip_text** out);
+int sdmi_clip_text_num_weights(const sdmi_clip_text* c);
+int sdmi_clip_text_weight_info(const sdmi_clip_text* c, int index, const char** key, int64_t* shape4, int* ndim);
+int sdmi_clip_text_set_weight(sdmi_clip_text* c, const char* key, const void* dev_ptr, const int64_t* shape,
+                              int ndim, int dtype, void* stream);
+int sdmi_clip_text_finalize(sdmi_clip_text* c, void* stream);
+/* token_ids: device int64 [batch][tokens] (tokens <= max_positions, causal attention, no padding mask, as
+ * the reference calls the model); out: fp32 [batch][tokens][hidden] = last_hidden_state. */
+int sdmi_clip_text_forward(sdmi_clip_text* c, const int64_t* token_ids, void* out, int batch, int tokens,
+                           void* stream);
+void sdmi_clip_text_destroy(sdmi_clip_text* c);
+
 /* out = clamp((x + 1) / 2, 0, 1)   (txt2img.py:307) */
 int sdmi_to_image(const void* x, void* out, int64_t n, void* stream);
 /* out = uint8(255 * clamp((x + 1) / 2, 0, 1)), x fp32 NCHW [batch][channels][hw] -> out uint8 NHWC
@@ -206,7 +238,8 @@ int sdmi_conv2d(const void* a0, int c0, const void* a1, int c1, const void* w, c
 /* Split count the UNet executor uses for an (m x k) * (k x n) problem of this dtype (1 = no split);
  * callers that want the executor's schedule size `partial` from it.  No counterpart in the reference. */
 int sdmi_conv2d_splits(int m, int n, int k, int dtype);
-/* softmax(q k^T * scale) v per (batch, head)  (CrossAttention :2784-2796); impl 0 auto, 1 scalar */
+/* softmax(q k^T * scale) v per (batch, head)  (CrossAttention :2784-2796).  impl is a bit set:
+ * 1 = force the scalar fp32-math kernel, 2 = causal (query i sees keys 0..i: the text transformer's mask) */
 int sdmi_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
                    int batch, int heads, int nq, int nk, int d, float scale, int dtype, int impl, void* stream);
 /* timestep_embedding :2212-2232 (fp32 out [batch][dim]) */

@@ -334,15 +334,48 @@ def g10(sdm, model):
          std=post.std, z=z, z_mode=model.scale_factor * post.mode())
 
 
+@torch.no_grad()
+def g12():
+    """Text conditioner: the model FrozenCLIPEmbedder.forward runs (:2557-2574), i.e. the installed
+    transformers' CLIPTextModel in the ViT-L/14 text configuration, with synthesised weights and synthetic
+    token ids (the pretrained weights and the tokenizer vocabulary are downloads)."""
+    import transformers
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from oracle import clip_ref
+    clip = importlib.import_module("stable-diffusion_amd.clip")
+    c = clip.CLIP_VIT_L14_TEXT
+    cfg = CLIPTextConfig(vocab_size=c["vocab_size"], hidden_size=c["hidden_size"],
+                         intermediate_size=c["intermediate_size"], num_hidden_layers=c["num_hidden_layers"],
+                         num_attention_heads=c["num_attention_heads"],
+                         max_position_embeddings=c["max_position_embeddings"], hidden_act="quick_gelu",
+                         layer_norm_eps=c["layer_norm_eps"])
+    m = CLIPTextModel(cfg).eval()
+    sd = synth.synth_state_dict(clip.clip_text_param_shapes(), WSEED)
+    own = m.state_dict()
+    mapped = {}
+    for k in own:
+        src = k if k in sd else "text_model." + k
+        if src in sd:
+            mapped[k] = sd[src]
+    missing = [k for k in own if k not in mapped and not k.endswith("position_ids")]
+    assert not missing, missing
+    m.load_state_dict(mapped, strict=False)
+    ids = clip_ref.synthetic_token_ids(3)
+    out = m(input_ids=ids).last_hidden_state
+    save("g12_clip_text", ids=ids, last_hidden_state=out, transformers_version=np.asarray(transformers.__version__))
+
+
 def main(argv):
-    names = argv or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g9b", "g7", "g10", "g11"]
+    names = argv or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g9b", "g7", "g10", "g11", "g12"]
     torch.manual_seed(0)
     sdm = import_reference()
     model = None
     need_model = {"g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"} & set(names)
     for n in names:
         t0 = time.time()
-        if n == "g1":
+        if n == "g12":
+            g12()
+        elif n == "g1":
             g1(sdm)
         elif n == "g2":
             g2(sdm)

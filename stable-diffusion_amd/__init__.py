@@ -1,7 +1,7 @@
 """sdmi -- MI355X-native Stable-Diffusion-v1 denoising hot path.
 
 Python mirror of the reference's inference-side classes (UNetModel, DiffusionWrapper,
-LatentDiffusion, DDIMSampler, AutoencoderKL) over hand-written gfx950 kernels in libsdmi.so.
+LatentDiffusion, DDIMSampler, AutoencoderKL, FrozenCLIPEmbedder) over hand-written gfx950 kernels in libsdmi.so.
 Importing the package needs neither the library nor a GPU; using a model does.
 """
 from .structure import (sd_v1_unet_config, sd_v1_ddconfig, sd_v1_model_params, unet_structure,
@@ -24,4 +24,7 @@ def __getattr__(name):
     if name in ("AutoencoderKL", "DiagonalGaussianDistribution"):
         from . import autoencoder
         return getattr(autoencoder, name)
+    if name in ("FrozenCLIPEmbedder", "clip_text_param_shapes", "CLIP_VIT_L14_TEXT"):
+        from . import clip
+        return getattr(clip, name)
     raise AttributeError(name)

@@ -32,6 +32,11 @@ class VaeCfg(ctypes.Structure):
                 ("compute_dtype", c_int)]
 
 
+class ClipCfg(ctypes.Structure):
+    _fields_ = [("vocab_size", c_int), ("hidden", c_int), ("intermediate", c_int), ("layers", c_int),
+                ("heads", c_int), ("max_positions", c_int), ("ln_eps", c_float), ("compute_dtype", c_int)]
+
+
 # name -> (restype, argtypes); every symbol of include/sdmi.h
 SIGNATURES = {
     "sdmi_version": (c_int, []),
@@ -61,6 +66,13 @@ SIGNATURES = {
     "sdmi_vae_decoder_finalize": (c_int, [c_void_p, c_void_p]),
     "sdmi_vae_decoder_forward": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sdmi_vae_decoder_destroy": (None, [c_void_p]),
+    "sdmi_clip_text_create": (c_int, [P(ClipCfg), P(c_void_p)]),
+    "sdmi_clip_text_num_weights": (c_int, [c_void_p]),
+    "sdmi_clip_text_weight_info": (c_int, [c_void_p, c_int, P(c_char_p), P(c_int64), P(c_int)]),
+    "sdmi_clip_text_set_weight": (c_int, [c_void_p, c_char_p, c_void_p, P(c_int64), c_int, c_int, c_void_p]),
+    "sdmi_clip_text_finalize": (c_int, [c_void_p, c_void_p]),
+    "sdmi_clip_text_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "sdmi_clip_text_destroy": (None, [c_void_p]),
     "sdmi_vae_encoder_create": (c_int, [P(VaeCfg), P(c_void_p)]),
     "sdmi_vae_encoder_num_weights": (c_int, [c_void_p]),
     "sdmi_vae_encoder_weight_info": (c_int, [c_void_p, c_int, P(c_char_p), P(c_int64), P(c_int)]),

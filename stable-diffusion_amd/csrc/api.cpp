@@ -201,7 +201,7 @@ int sdmi_attention(const void* q, int ldq, const void* k, int ldk, const void* v
                    int batch, int heads, int nq, int nk, int d, float scale, int dtype, int impl, void* stream) {
   AttentionArgs a;
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo;
-  a.B = batch; a.heads = heads; a.Nq = nq; a.Nk = nk; a.d = d; a.scale = scale; a.dtype = dtype; a.impl = impl;
+  a.B = batch; a.heads = heads; a.Nq = nq; a.Nk = nk; a.d = d; a.scale = scale; a.dtype = dtype; a.impl = impl & 1; a.causal = (impl >> 1) & 1;
   return attention(a, (hipStream_t)stream);
 }
 

@@ -51,6 +51,7 @@ struct FlashParams {
   int ldq, ldk, ldv, ldo;      // in elements
   int B, heads, Nq, Nk;
   float c;                     // scale * log2(e)
+  int causal;                  // keys beyond the query's own index are masked
 };
 
 constexpr int KV_TILE = 64;
@@ -186,6 +187,16 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_flash_kernel(Flas
       }
     }
 
+    if (p.causal && t * KV_TILE + KV_TILE - 1 > blockIdx.x * 128 + wid * 32) {
+      const int kbase_i = t * KV_TILE + 4 * h;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = kbase_i + (i & 3) + 8 * (i >> 2);
+        if (key > qrow) s0[i] = -INFINITY;
+        if (key + 32 > qrow) s1[i] = -INFINITY;
+      }
+    }
+
     // ---- online softmax (per lane = per query; partner lane ^ 32 holds the other keys) ----------
     // The running maximum only moves when some query of the wave outgrows it by more than 2^8: P stays
     // below 256 (exact range of both 16-bit formats, fp32 sums), and almost every tile skips the
@@ -276,6 +287,7 @@ int launch_flash(const AttentionArgs& a, hipStream_t stream) {
   p.ldq = a.ldq; p.ldk = a.ldk; p.ldv = a.ldv; p.ldo = a.ldo;
   p.B = a.B; p.heads = a.heads; p.Nq = a.Nq; p.Nk = a.Nk;
   p.c = a.scale * 1.4426950408889634f;
+  p.causal = a.causal;
   const int lds = 2 * G::STAGE;
   dim3 grid((a.Nq + 127) / 128, a.B * a.heads);
   hipLaunchKernelGGL((attn_flash_kernel<T, D>), grid, dim3(256), lds, stream, p);
@@ -304,7 +316,7 @@ int attention(const AttentionArgs& a, hipStream_t stream) {
   char label[64];
   snprintf(label, sizeof(label), "B%d h%d Nq%d Nk%d d%d", a.B, a.heads, a.Nq, a.Nk, a.d);
   ProfScope prof(PROF_ATTENTION, stream, 4.0 * a.B * a.heads * (double)a.Nq * a.Nk * a.d, 0.0, label);
-  if (a.impl != 1 && a.dtype != SDMI_F32) {
+  if (!(a.impl & 1) && a.dtype != SDMI_F32) {
     SDMI_TRY(attention_init());
     SDMI_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 4 == 0,
                  "attention: row strides must be multiples of 8 elements");

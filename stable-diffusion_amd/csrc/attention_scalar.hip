@@ -13,6 +13,7 @@ struct AttnParams {
   int ldq, ldk, ldv, ldo;
   int B, heads, Nq, Nk, d;
   float scale;
+  int causal;
   int tk;           // keys per LDS tile
 };
 
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void attn_scalar_kernel(AttnParams p) {
           }
         }
         for (int o = 1; o < lpq; o <<= 1) part += __shfl_xor(part, o, 64);
-        s[jj] = j < nk ? part : -INFINITY;
+        s[jj] = (j < nk && !(p.causal && k0 + j > qrow)) ? part : -INFINITY;
         cmax = fmaxf(cmax, s[jj]);
       }
       const float mnew = fmaxf(mrun, cmax);
@@ -119,7 +120,7 @@ int launch_dpl(const AttentionArgs& a, hipStream_t stream) {
   AttnParams p;
   p.q = a.q; p.k = a.k; p.v = a.v; p.out = a.out;
   p.ldq = a.ldq; p.ldk = a.ldk; p.ldv = a.ldv; p.ldo = a.ldo;
-  p.B = a.B; p.heads = a.heads; p.Nq = a.Nq; p.Nk = a.Nk; p.d = a.d; p.scale = a.scale;
+  p.B = a.B; p.heads = a.heads; p.Nq = a.Nq; p.Nk = a.Nk; p.d = a.d; p.scale = a.scale; p.causal = a.causal;
   const int lpq = a.d / DPL;
   int tk = 64;
   while (tk > 8 && (size_t)2 * tk * a.d * sizeof(T) > 48 * 1024) tk >>= 1;

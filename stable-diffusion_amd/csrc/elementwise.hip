@@ -334,6 +334,33 @@ __global__ void pack_inconv_weight_kernel(const float* w, float* out, int O, int
   }
 }
 
+// token + position embedding lookup: x[b][t][:] = tok[ids[b][t]][:] + pos[t][:]   (fp32 tables -> T)
+template <typename T>
+__global__ void embed_tokens_kernel(const int64_t* ids, const float* tok, const float* pos, T* out, int rows,
+                                    int T_len, int d, int vocab) {
+  const int dv = d / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)rows * dv;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / dv), c = (int)(i - (int64_t)row * dv) * 4;
+    int64_t id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);       // the host wrapper rejects out-of-range ids
+    const float4 a = *reinterpret_cast<const float4*>(tok + (size_t)id * d + c);
+    const float4 b = *reinterpret_cast<const float4*>(pos + (size_t)(row % T_len) * d + c);
+    T* o = out + (size_t)row * d + c;
+    o[0] = from_f32<T>(a.x + b.x); o[1] = from_f32<T>(a.y + b.y);
+    o[2] = from_f32<T>(a.z + b.z); o[3] = from_f32<T>(a.w + b.w);
+  }
+}
+
+// x * sigmoid(1.702 x), in place
+template <typename T>
+__global__ void quick_gelu_kernel(T* x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = to_f32<T>(x[i]);
+    x[i] = from_f32<T>(v / (1.0f + __expf(-1.702f * v)));
+  }
+}
+
 template <typename T>
 __global__ void convert_f32_kernel(const float* x, T* out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -599,6 +626,24 @@ int pack_outconv_weight(const float* w, float* out, int O, int I, hipStream_t s)
   SDMI_REQUIRE(w && out, "pack_outconv_weight: null pointer");
   hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(grid_for((size_t)O * I * 9)), dim3(256), 0, s, w, out, O,
                      I, 9);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int embed_tokens(const int64_t* ids, const float* tok, const float* pos, void* out, int rows, int T_len, int d,
+                 int vocab, int dtype, hipStream_t s) {
+  SDMI_REQUIRE(ids && tok && pos && out && rows > 0 && T_len > 0 && d % 4 == 0 && vocab > 0, "embed_tokens: bad arguments");
+  SDMI_DISPATCH_DTYPE(dtype, T,
+                      hipLaunchKernelGGL(embed_tokens_kernel<T>, dim3(grid_for((size_t)rows * (d / 4))), dim3(256), 0,
+                                         s, ids, tok, pos, (T*)out, rows, T_len, d, vocab));
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int quick_gelu(void* x, int64_t n, int dtype, hipStream_t s) {
+  SDMI_REQUIRE(x && n > 0, "quick_gelu: bad arguments");
+  SDMI_DISPATCH_DTYPE(dtype, T,
+                      hipLaunchKernelGGL(quick_gelu_kernel<T>, dim3(grid_for((size_t)n)), dim3(256), 0, s, (T*)x, n));
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

@@ -85,6 +85,7 @@ struct AttentionArgs {
   float scale = 1.f;
   int dtype = SDMI_F16;
   int impl = 0;                           // 0 = auto, 1 = force the scalar (fp32-math) kernel
+  int causal = 0;                         // 1: query i attends keys 0..i only (text transformer)
 };
 int attention(const AttentionArgs& a, hipStream_t stream);
 int attention_init();   // one-time kernel attribute setup; call outside stream capture
@@ -127,10 +128,12 @@ int gaussian_sample(const float* moments, const float* noise, float scale, float
 int ddim_step(const float* x, const float* eps, int cfg, float scale, float a_t, float a_prev,
               float sigma, float sqrt_1m_at, const float* noise, float temperature, float* x_prev,
               float* pred_x0, int64_t n, hipStream_t s);
-// out = ca * a + cb * b   (stochastic_encode / q_sample with per-call scalars; fp32)
+// DDPM ancestral update with the schedule tables' entries at the step's timestep as scalars (fp32):
+//   x0 = c_recip x - c_recipm1 eps (clamped to [-1,1] if clip); x_prev = coef1 x0 + coef2 x + noise_coef (noise temperature)
 int ddpm_step(const float* x, const float* eps, float c_recip, float c_recipm1, int clip, float coef1, float coef2,
               float noise_coef, const float* noise, float temperature, float* x_prev, float* pred_x0, int64_t n,
               hipStream_t s);
+// out = ca * a + cb * b   (stochastic_encode / q_sample with per-call scalars; fp32)
 int axpby(const float* a, const float* b, float ca, float cb, float* out, int64_t n, hipStream_t s);
 // row softmax over fp32 scores -> dtype probabilities (VAE mid-block attention, two-pass path)
 int softmax_rows(const float* s, void* p, int rows, int cols, float scale, int dtype, hipStream_t st);
@@ -150,5 +153,9 @@ int pack_geglu_weight(const float* w, const float* b, void* wout, float* bout, i
 int pack_inconv_weight(const float* w, float* out, int O, int I, hipStream_t s);
 // OIHW fp32 -> [O][tap][I] fp32 for out_conv
 int pack_outconv_weight(const float* w, float* out, int O, int I, hipStream_t s);
+// text transformer: x[row][:] = tok[ids[row]][:] + pos[row % T_len][:] (fp32 tables, dtype out); x * sigmoid(1.702 x)
+int embed_tokens(const int64_t* ids, const float* tok, const float* pos, void* out, int rows, int T_len, int d,
+                 int vocab, int dtype, hipStream_t s);
+int quick_gelu(void* x, int64_t n, int dtype, hipStream_t s);
 int convert_f32(const float* x, void* out, int64_t n, int dtype, hipStream_t s);
 int convert_to_f32(const void* x, float* out, int64_t n, int dtype, hipStream_t s);

@@ -64,7 +64,9 @@ class LatentDiffusion:
         self.model = DiffusionWrapper(unet_config, conditioning_key, compute_dtype=compute_dtype, device=self.device)
         self.first_stage_model = AutoencoderKL(**{k: v for k, v in first_stage_config.items() if k != "monitor"},
                                                compute_dtype=compute_dtype, device=self.device)
+        # the text transformer is built when its weights (cond_stage_model.transformer.*) are loaded
         self.cond_stage_model = None
+        self.cond_stage_config = cond_stage_config
         self.register_schedule(given_betas=given_betas, beta_schedule=beta_schedule, timesteps=timesteps,
                                linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
 
@@ -107,17 +109,29 @@ class LatentDiffusion:
         self.model.diffusion_model.load_state_dict(state_dict, strict=False, prefix="model.diffusion_model.")
         self.first_stage_model.load_state_dict(state_dict, strict=False, prefix="first_stage_model.")
         known = ("model.diffusion_model.", "first_stage_model.")
+        if any(k.startswith("cond_stage_model.transformer.") for k in state_dict):
+            from .clip import FrozenCLIPEmbedder
+            params = {}
+            if isinstance(self.cond_stage_config, dict):
+                params = {k: v for k, v in (self.cond_stage_config.get("params") or {}).items()
+                          if k in ("version", "max_length", "tokenizer", "config")}
+            self.cond_stage_model = FrozenCLIPEmbedder(device=self.device, compute_dtype=self.compute_dtype, **params)
+            self.cond_stage_model.load_state_dict(state_dict, prefix="cond_stage_model.")
+            known = known + ("cond_stage_model.",)
         unexpected = [k for k in state_dict if not k.startswith(known)]
         return [], unexpected
 
     # ---- conditioning ------------------------------------------------------------------------------
     def get_learned_conditioning(self, c):
-        """The reference runs FrozenCLIPEmbedder here (:4408); on this path the conditioning is already
-        a (B,77,context_dim) tensor and is returned as is."""
-        if torch.is_tensor(c):
+        """``self.cond_stage_model.encode(c)`` (:4408-4420).  A floating-point tensor is taken to be the
+        (B,77,context_dim) conditioning itself and returned as is; token ids (an integer tensor) or text go
+        through the text transformer when its weights were loaded."""
+        if torch.is_tensor(c) and c.is_floating_point():
             return c.to(self.device)
-        raise NotImplementedError("text encoding is outside the MI355X denoising path: pass the "
-                                  "(B,77,768) CLIP hidden states as a tensor")
+        if self.cond_stage_model is None:
+            raise NotImplementedError("no text transformer weights (cond_stage_model.transformer.*) were loaded: "
+                                      "pass the (B,77,768) CLIP hidden states as a tensor")
+        return self.cond_stage_model.encode(c)
 
     # ---- denoiser --------------------------------------------------------------------------------
     def apply_model(self, x_noisy, t, cond, return_ids=False, out=None):

@@ -104,8 +104,9 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return out
 
 
-def attention(q, k, v, heads, scale=None, impl=0):
+def attention(q, k, v, heads, scale=None, impl=0, causal=False):
     """q: (B,Nq,heads*d), k/v: (B,Nk,heads*d) (may be strided views over the last dim) -> (B,Nq,heads*d)."""
+    impl = (impl & 1) | (2 if causal else 0)
     B, Nq, C = q.shape
     Nk = k.shape[1]
     d = C // heads

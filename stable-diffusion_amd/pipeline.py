@@ -15,9 +15,10 @@ from .structure import sd_v1_model_params
 
 
 def build_synthetic_model(in_channels=4, conditioning_key="crossattn", dtype="fp16", seed=0, device="cuda",
-                          encoder=False):
+                          encoder=False, text_encoder=False):
     """LatentDiffusion with SD-v1-shaped weights from the deterministic synthesiser (no checkpoint
-    exists offline).  Hash keys are the un-prefixed checkpoint names."""
+    exists offline).  Hash keys are the un-prefixed checkpoint names.  ``encoder`` adds the VAE encoder,
+    ``text_encoder`` the CLIP ViT-L/14 text transformer (``cond_stage_model.transformer.*``)."""
     from .ddpm import LatentDiffusion
     params = sd_v1_model_params(in_channels, conditioning_key)
     model = LatentDiffusion(**params, compute_dtype=dtype, device=device)
@@ -25,8 +26,26 @@ def build_synthetic_model(in_channels=4, conditioning_key="crossattn", dtype="fp
           for k, s in model.model.diffusion_model.state_dict_shapes().items()}
     sd.update({"first_stage_model." + k: synth.synth_tensor(seed, k, s, device)
                for k, s in model.first_stage_model.state_dict_shapes(encoder=encoder).items()})
+    if text_encoder:
+        from .clip import clip_text_param_shapes
+        sd.update({"cond_stage_model.transformer." + k: synth.synth_tensor(seed, k, s, device)
+                   for k, s in clip_text_param_shapes().items()})
     model.load_state_dict(sd)
     return model
+
+
+def synthetic_prompt_tokens(batch, device="cuda", first_sample=0, tokens=77, vocab=49408):
+    """Stand-ins for the tokenizer's output (its vocabulary is a download): per global sample index, BOS, a
+    run of 6..37 pseudo-random word ids, then EOS padding to `tokens`; and the empty prompt (BOS, EOS...)."""
+    c = torch.full((batch, tokens), vocab - 1, dtype=torch.long)
+    c[:, 0] = vocab - 2
+    for i in range(batch):
+        g = first_sample + i
+        n = 6 + g % 32
+        c[i, 1:1 + n] = (synth.uniform01(3, f"prompt.{g}", n) * (vocab - 2)).long()
+    uc = torch.full((batch, tokens), vocab - 1, dtype=torch.long)
+    uc[:, 0] = vocab - 2
+    return uc.to(device), c.to(device)
 
 
 def synthetic_conditioning(batch, device="cuda", first_sample=0):
@@ -44,11 +63,16 @@ def initial_latents(batch, h, w, device="cuda", first_sample=0, seed=42):
 
 @torch.no_grad()
 def txt2img(model, x_T, uc, c, steps=50, scale=7.5, eta=0.0, sampler=None):
-    """One batch through the whole path; returns images (B,3,8h,8w) in [0,1] and the final latents."""
+    """One batch through the whole path; returns images (B,3,8h,8w) in [0,1] and the final latents.
+    ``uc`` / ``c`` are conditioning tensors (B,77,768), or token ids / text for the model's text transformer
+    (txt2img.py:285-290: get_learned_conditioning of the empty prompt and of the prompts)."""
     from . import ops
     from .ddim import DDIMSampler
     sampler = sampler or DDIMSampler(model)
     b, _, h, w = x_T.shape
+    c = model.get_learned_conditioning(c)
+    if scale != 1.0:
+        uc = model.get_learned_conditioning(uc)
     cond = torch.cat([uc, c]) if scale != 1.0 else c
     z, _ = sampler.sample(S=steps, batch_size=b, shape=[4, h, w], conditioning=cond,
                           unconditional_guidance_scale=scale,

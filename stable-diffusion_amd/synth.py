@@ -82,7 +82,7 @@ def synth_tensor(seed: int, key: str, shape, device="cpu") -> torch.Tensor:
 def _is_norm_key(key: str) -> bool:
     parts = key.split(".")
     name = parts[-2]
-    if name.startswith("norm"):          # norm, norm1..3, norm_out
+    if name.startswith("norm") or "layer_norm" in name:   # norm, norm1..3, norm_out; the text transformer's
         return True
     # GroupNorm32 inside nn.Sequential: in_layers.0 / out_layers.0 / out.0
     if name == "0" and parts[-3] in ("in_layers", "out_layers", "out"):

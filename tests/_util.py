@@ -15,7 +15,8 @@ synth = importlib.import_module("stable-diffusion_amd.synth")
 def golden(name):
     path = os.path.join(GOLD, name + ".npz")
     z = np.load(path, allow_pickle=False)
-    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+    # text entries (e.g. the version of the library that produced a vector) stay python strings
+    return {k: (str(z[k]) if z[k].dtype.kind in "US" else torch.from_numpy(np.asarray(z[k]))) for k in z.files}
 
 
 def max_rel_err(a, b):

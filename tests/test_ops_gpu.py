@@ -300,6 +300,25 @@ def test_attention_ramping_scores(ops, d):
         assert max_rel_err(y.float().cpu(), ref) < TOL[dt] * 2
 
 
+@pytest.mark.parametrize("N,d,heads", [(77, 64, 12), (200, 64, 4), (333, 40, 8)])
+def test_attention_causal(ops, N, d, heads):
+    """Causal mask of the text transformer (query i sees keys 0..i), one and several key tiles, both kernels."""
+    B, C = 2, heads * d
+    qv = rnd(f"attc{N}.q", (B, N, C), -2., 2.)
+    kv = rnd(f"attc{N}.k", (B, N, C), -2., 2.)
+    vv = rnd(f"attc{N}.v", (B, N, C), -1., 1.)
+    mask = torch.full((N, N), float("-inf")).triu(1)
+    for dt in ("fp32", "fp16", "bf16"):
+        qq, kk, vq = q(qv, dt), q(kv, dt), q(vv, dt)
+        sp = lambda t: t.reshape(B, N, heads, d).transpose(1, 2).double()
+        w = (sp(qq) @ sp(kk).transpose(-1, -2)) * d ** -0.5 + mask
+        ref = (w.softmax(-1) @ sp(vq)).transpose(1, 2).reshape(B, N, C).float()
+        dev = lambda t: t.cuda().to(tdt(dt))
+        for impl in ((1,) if dt == "fp32" else (0, 1)):
+            y = ops.attention(dev(qq), dev(kk), dev(vq), heads, impl=impl, causal=True)
+            assert max_rel_err(y.float().cpu(), ref) < TOL[dt] * 2, (dt, impl)
+
+
 def test_to_image_u8_and_inpaint_composite(ops):
     """Bit-exact against the scripts' post-processing (txt2img.py:307,316-317; inpaint_with_text.py:286-291)."""
     x = rnd("u8.x", (2, 3, 24, 40), -1.3, 1.3)

@@ -5,6 +5,8 @@ order, so agreement is at rounding level; bounds below are max|a-b|/max|b|.
 """
 from collections import OrderedDict
 
+import importlib
+
 import numpy as np
 import pytest
 import torch
@@ -145,6 +147,19 @@ def test_g11_ddpm_kat():
                 assert torch.equal(xp, g[f"t{tv}.clip{int(clip)}.temp{temp}.x_prev"])
     xp, x0 = sampler_ref.ddpm_update(x, eps, torch.tensor([7, 0]), tab, noise)
     assert torch.equal(xp, g["t7_0.x_prev"]) and torch.equal(x0, g["t7_0.x0"])
+
+
+def test_g12_clip_text():
+    """The text-transformer restatement equals the installed transformers' CLIPTextModel (ViT-L/14 text
+    configuration, synthesised weights, synthetic ids) on the stored vector."""
+    from oracle import clip_ref
+    clip = importlib.import_module("stable-diffusion_amd.clip")
+    g = golden("g12_clip_text")
+    sd = synth.synth_state_dict(clip.clip_text_param_shapes(), 0)
+    assert torch.equal(g["ids"], clip_ref.synthetic_token_ids(3))
+    out = clip_ref.clip_text_forward(sd, g["ids"])
+    assert out.shape == (3, 77, 768)
+    assert max_rel_err(out, g["last_hidden_state"]) < 1e-5
 
 
 def _vae():

@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdmi.so")
+LIB_PATH = os.environ.get("SDMI_LIB") or os.path.join(_HERE, "libsdmi.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 c_void_p, c_int, c_float, c_int64, c_char_p = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,

@@ -183,8 +183,8 @@ __device__ __forceinline__ void store_wave_tile(const GemmParams& p, f32x4 (&acc
 // (GEGLU gate applied on the way in, the residual on the way out, in fp32, one rounding).  OutT is
 // the stored type: T, or float for split-K slabs and fp32 outputs.  `strip` must hold
 // 16 * (16 * NO + 4) floats, NO = output fragments per row.
-template <typename T, typename OutT, int NI, bool G>
-__device__ __forceinline__ void store_wave_tile_lds(const GemmParams& p, f32x4 (&acc)[NI][4], float* strip,
+template <typename T, typename OutT, int NI, bool G, int MJ = 4>
+__device__ __forceinline__ void store_wave_tile_lds(const GemmParams& p, f32x4 (&acc)[NI][MJ], float* strip,
                                                     OutT* out, int ldo, int m_wave, int n_wave, int lane) {
   constexpr int NO = G ? NI / 2 : NI;
   constexpr int ROWF = NO * 16 + 4;
@@ -208,7 +208,7 @@ __device__ __forceinline__ void store_wave_tile_lds(const GemmParams& p, f32x4 (
   }
   const bool has_resid = p.resid != nullptr;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < MJ; ++j) {
     Tres res[KI];
     if (has_resid) {
 #pragma unroll
@@ -450,11 +450,11 @@ __global__ __launch_bounds__(S::NTHREADS) void conv_gemm_kernel(GemmParams p) {
 // t+NSTAGE into that stage is issued no earlier than that segment.  Every wave waits for its own
 // DMA of tile t+1 (counted vmcnt: with three stages tile t+2 stays in flight) before the last
 // barrier that precedes group 0's first read of it.
-template <int NFW_, int NPH_, int NSTAGE_> struct PPShape {
-  static constexpr int NFW = NFW_, NPH = NPH_, NSTAGE = NSTAGE_;
+template <int NFW_, int NPH_, int NSTAGE_, int MJ_ = 4> struct PPShape {
+  static constexpr int NFW = NFW_, NPH = NPH_, NSTAGE = NSTAGE_, MJ = MJ_;   // MJ: 16-row fragments per wave
   static constexpr int NFP = NFW / NPH;                             // fragments per phase
-  static constexpr int BM = 256, BN = 32 * NFW, NTHREADS = 512;
-  static constexpr int AP = 4;                                      // 1-KiB activation pieces per wave and tile
+  static constexpr int BM = 64 * MJ, BN = 32 * NFW, NTHREADS = 512;
+  static constexpr int AP = MJ;                                     // 1-KiB activation pieces per wave and tile
   static constexpr int WPT = BN / 8, WP_LO = WPT / 8, WP_REM = WPT % 8;   // weight pieces: waves < WP_REM take one more
   static constexpr int WP_MAX = WP_LO + (WP_REM ? 1 : 0);
   static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
@@ -465,11 +465,13 @@ template <int NFW_, int NPH_, int NSTAGE_> struct PPShape {
 typedef PPShape<10, 2, 2> PP320;
 typedef PPShape<8, 2, 2> PP256;
 typedef PPShape<5, 1, 3> PP160;
+typedef PPShape<5, 1, 3, 2> PP160H;     // 128x160: layers whose 256-row tiles would leave CUs idle
 
 template <typename T, typename S>
 __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit operands only");
-  constexpr int BK = 64, AP = S::AP, NFW = S::NFW, NFP = S::NFP, NPH = S::NPH, NSTAGE = S::NSTAGE;
+  constexpr int BK = 64, AP = S::AP, NFW = S::NFW, NFP = S::NFP, NPH = S::NPH, NSTAGE = S::NSTAGE, MJ = S::MJ;
+  constexpr int WROWS = 16 * MJ;                                     // rows of a wave's tile
   typedef typename Frag<T>::type frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   // The accumulators start from the per-column bias and the per-(sample, column) time-embedding term
   // (when this launch owns the epilogue): their loads overlap the first tile's DMA and the epilogue
   // is left with the residual only.
-  f32x4 acc[NFW][4];
+  f32x4 acc[NFW][MJ];
   const bool own_epilogue = p.partial == nullptr;
   {
     const int ncol = n0 + grp * (S::BN / 2) + fq * 4;
@@ -587,12 +589,12 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
       f32x4 bv = {0.f, 0.f, 0.f, 0.f};
       if (own_epilogue && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + ncol + i * 16);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = bv;
+      for (int j = 0; j < MJ; ++j) acc[i][j] = bv;
     }
     if (own_epilogue && p.rowadd) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int m = min(m0 + wr * 64 + j * 16 + frow, p.M - 1);
+      for (int j = 0; j < MJ; ++j) {
+        const int m = min(m0 + wr * WROWS + j * 16 + frow, p.M - 1);
         const float* ra = p.rowadd + (size_t)(m / hw) * p.ldra + ncol;
 #pragma unroll
         for (int i = 0; i < NFW; ++i) acc[i][j] += *reinterpret_cast<const f32x4*>(ra + i * 16);
@@ -601,10 +603,10 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
     }
   }
   const int sw = frow & 7;
-  const int a_base = (wr * 64 + frow) * 128;
+  const int a_base = (wr * WROWS + frow) * 128;
   const int w_base = S::A_BYTES + (grp * (S::BN / 2) + frow) * 128;
 
-  frag_t af[4], wf[NFP];
+  frag_t af[MJ], wf[NFP];
 
   // ---- prologue: the first NSTAGE-1 tiles are put in flight, tile 0 is made visible to everyone,
   // then the groups are staggered ----------------------------------------------------------------
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
       // read segment
       if (h == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const frag_t*>(sb + a_base + j * 2048 + coff);
+        for (int j = 0; j < MJ; ++j) af[j] = *reinterpret_cast<const frag_t*>(sb + a_base + j * 2048 + coff);
       }
 #pragma unroll
       for (int i = 0; i < NFP; ++i)
@@ -648,7 +650,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < NFP; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[h * NFP + i][j] = mma(wf[i], af[j], acc[h * NFP + i][j]);
+        for (int j = 0; j < MJ; ++j) acc[h * NFP + i][j] = mma(wf[i], af[j], acc[h * NFP + i][j]);
       __builtin_amdgcn_s_setprio(0);
       if (ph == 2 * NPH - 1 && grp == 0) {
         if (keep) wait_keep_one_tile();
@@ -667,32 +669,34 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < NFW; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+      for (int j = 0; j < MJ; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
   GemmParams pe = p;
   if (own_epilogue) { pe.bias = nullptr; pe.rowadd = nullptr; }      // already in the accumulators
-  const int m_wave = m0 + wr * 64, n_wave = n0 + grp * (S::BN / 2);
+  const int m_wave = m0 + wr * WROWS, n_wave = n0 + grp * (S::BN / 2);
   if (p.wide_store) {
     // all stage reads and DMAs are retired behind the last barrier: the stages are free
     float* strip = reinterpret_cast<float*>(smem + wid * (16 * (16 * NFW + 4) * 4));
     static_assert(8 * 16 * (16 * NFW + 4) * 4 <= S::LDS_BYTES, "strips do not fit");
     if (p.partial) {
       pe.resid = nullptr; pe.dup_rows = 0;                           // applied by the reduction pass
-      store_wave_tile_lds<T, float, NFW, false>(pe, acc, strip, p.partial + (size_t)blockIdx.y * p.M * p.N, p.N,
-                                                m_wave, n_wave, lane);
+      store_wave_tile_lds<T, float, NFW, false, MJ>(pe, acc, strip, p.partial + (size_t)blockIdx.y * p.M * p.N, p.N,
+                                                    m_wave, n_wave, lane);
     } else if (p.out_f32) {
-      store_wave_tile_lds<T, float, NFW, false>(pe, acc, strip, reinterpret_cast<float*>(p.out), p.ldo, m_wave,
-                                                n_wave, lane);
+      store_wave_tile_lds<T, float, NFW, false, MJ>(pe, acc, strip, reinterpret_cast<float*>(p.out), p.ldo, m_wave,
+                                                    n_wave, lane);
     } else if (NFW % 2 == 0 && p.geglu) {
       if constexpr (NFW % 2 == 0)
-        store_wave_tile_lds<T, T, NFW, true>(pe, acc, strip, reinterpret_cast<T*>(p.out), p.ldo, m_wave, n_wave, lane);
+        store_wave_tile_lds<T, T, NFW, true, MJ>(pe, acc, strip, reinterpret_cast<T*>(p.out), p.ldo, m_wave, n_wave,
+                                                 lane);
     } else {
-      store_wave_tile_lds<T, T, NFW, false>(pe, acc, strip, reinterpret_cast<T*>(p.out), p.ldo, m_wave, n_wave, lane);
+      store_wave_tile_lds<T, T, NFW, false, MJ>(pe, acc, strip, reinterpret_cast<T*>(p.out), p.ldo, m_wave, n_wave,
+                                                lane);
     }
     return;
   }
-  store_wave_tile<T, NFW, 4>(pe, acc, m_wave + frow, n_wave, fq);
+  store_wave_tile<T, NFW, MJ>(pe, acc, m_wave + frow, n_wave, fq);
 }
 
 // split-K second pass: sum the fp32 slabs and run the same epilogue.  One thread per 4 columns.
@@ -737,6 +741,8 @@ int set_lds_limits() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP256::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP160H::LDS_BYTES));
   }
   return SDMI_OK;
 }
@@ -765,11 +771,12 @@ namespace {
 // the workgroups are dealt to the CUs in rounds (512 small blocks or 256 large ones per round), a
 // round takes (K-tiles per split) x (time of one K-tile of that shape), and split-K adds the slab
 // round trip through HBM plus a launch.  The K-tile times are measured on MI355X with full grids.
-enum { KIND_SMALL = 0, KIND_PP320 = 1, KIND_PP256 = 2, KIND_PP160 = 3 };
+enum { KIND_SMALL = 0, KIND_PP320 = 1, KIND_PP256 = 2, KIND_PP160 = 3, KIND_PP160H = 4 };
 struct Plan { int kind, splits; };
 
 // SDMI_GEMM_SHAPE (tests, experiments; read on every call): 1 = 128x128 tiles only, 2 = 256x320 /
-// 256x256 tiles wherever they are legal, 3 = 256x160 tiles wherever they are legal.
+// 256x256 tiles wherever they are legal, 3 = 256x160 tiles wherever they are legal, 4 = 128x160 likewise,
+// 5 = never 128x160.
 int forced_kind() {
   const char* e = getenv("SDMI_GEMM_SHAPE");
   return e ? atoi(e) : 0;
@@ -779,6 +786,7 @@ constexpr double T_KT_SMALL_US = 1.40;    // 128x128x64 K-tile, two blocks per C
 constexpr double T_KT_PP320_US = 2.10;    // 256x320x64 K-tile, one block per CU
 constexpr double T_KT_PP256_US = 1.75;    // 256x256x64
 constexpr double T_KT_PP160_US = 1.20;    // 256x160x64
+constexpr double T_KT_PP160H_US = 0.80;   // 128x160x64 (only offered for short K loops, see make_plan)
 
 double split_cost_us(int M, int N, int splits) {
   if (splits <= 1) return 0.0;
@@ -810,17 +818,28 @@ Plan make_plan(int M, int N, int K, int dtype, bool geglu) {
     best_t = (double)((blocks + 511) / 512) * (per + 1.5) * T_KT_SMALL_US + split_cost_us(M, N, best.splits);
   }
   bool found = false;
-  for (int kind = KIND_PP320; kind <= KIND_PP160; ++kind) {
+  for (int kind = KIND_PP320; kind <= KIND_PP160H; ++kind) {
     const int bn = kind == KIND_PP320 ? 320 : (kind == KIND_PP256 ? 256 : 160);
+    const int bm = kind == KIND_PP160H ? 128 : 256;
     if (N % bn != 0) continue;
-    if (kind == KIND_PP160 && (geglu || forced_kind() == 2)) continue;      // odd fragment count: no (value, gate) pairs
-    const double tk = kind == KIND_PP320 ? T_KT_PP320_US : (kind == KIND_PP256 ? T_KT_PP256_US : T_KT_PP160_US);
-    const long tiles = (long)((M + 255) / 256) * (N / bn);
+    const bool odd = kind == KIND_PP160 || kind == KIND_PP160H;       // odd fragment count: no (value, gate) pairs
+    if (odd && (geglu || forced_kind() == 2)) continue;
+    if (kind == KIND_PP160H && forced_kind() == 5) continue;
+    const double tk = kind == KIND_PP320 ? T_KT_PP320_US : (kind == KIND_PP256 ? T_KT_PP256_US :
+                      (kind == KIND_PP160 ? T_KT_PP160_US : T_KT_PP160H_US));
+    const long tiles = (long)((M + bm - 1) / bm) * (N / bn);
     for (int s = 1; s <= 16; ++s) {
       if (s > 1 && nkt / s < 8) break;
       const int per = (nkt + s - 1) / s;
+      // the 128-row shape pays its extra weight traffic back only while the per-tile fixed cost dominates:
+      // measured against 256x160 with split-K it wins up to about 32 K-tiles per workgroup
+      if (kind == KIND_PP160H && per > 32 && forced_kind() != 4) continue;
       const double t = (double)((tiles * s + 255) / 256) * (per + 3.0) * tk + split_cost_us(M, N, s);
-      if (t < best_t || (forced_kind() == 2 && !found) || (forced_kind() == 3 && kind == KIND_PP160 && best.kind != kind)) {
+      const bool force = (forced_kind() == 2 && !found) || (forced_kind() == 3 && kind == KIND_PP160 && best.kind != kind) ||
+                         (forced_kind() == 4 && kind == KIND_PP160H && best.kind != kind);
+      const bool locked = (forced_kind() == 3 && best.kind == KIND_PP160 && kind != KIND_PP160) ||
+                          (forced_kind() == 4 && best.kind == KIND_PP160H && kind != KIND_PP160H);
+      if ((t < best_t && !locked) || force) {
         best_t = t; best.kind = kind; best.splits = s; found = true;
       }
     }
@@ -897,6 +916,7 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
       if (kind == KIND_PP320) launch_pp<T, PP320>(p, splits, stream);
       else if (kind == KIND_PP256) launch_pp<T, PP256>(p, splits, stream);
       else if (kind == KIND_PP160) launch_pp<T, PP160>(p, splits, stream);
+      else if (kind == KIND_PP160H) launch_pp<T, PP160H>(p, splits, stream);
     }
     if (kind == KIND_SMALL || sizeof(T) != 2) {
       typedef ShapeSmall S;

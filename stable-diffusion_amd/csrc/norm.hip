@@ -251,48 +251,71 @@ int launch_gn(const GroupNormArgs& a, hipStream_t stream) {
   return SDMI_OK;
 }
 
-// ---- LayerNorm: one wave per row, row held in registers, two-pass (mean, then centred variance) --
-template <typename T, int MAXV>
+// ---- LayerNorm: one wave per R rows, rows held in registers, two-pass (mean, then centred variance).
+// R rows are loaded before the first reduction so that several 16-byte loads per lane are in flight and
+// the shuffle chains of the rows interleave.
+template <typename T, int MAXV, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, T* out, const float* gamma,
                                                         const float* beta, int rows, int d, float eps) {
   constexpr int EPV = VecOf<T>::N;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int row0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
   const int nvec = d / EPV;
-  float f[MAXV][EPV];
-  float s = 0.f;
+  float f[R][MAXV][EPV];
+  float s[R];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int v = lane + i * 64;
-    if (v < nvec) {
-      load_vec<T>(x + (size_t)row * d + v * EPV, f[i]);
+  for (int r = 0; r < R; ++r) {
+    s[r] = 0.f;
+    const int row = min(row0 + r, rows - 1);        // tail rows recompute the last row and do not store
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) s += f[i][e];
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + i * 64;
+      if (v < nvec) load_vec<T>(x + (size_t)row * d + v * EPV, f[r][i]);
     }
   }
-  const float mean = wave_sum(s) / (float)d;
-  float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int v = lane + i * 64;
-    if (v < nvec) {
+  for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) { const float t = f[i][e] - mean; q += t * t; }
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+    for (int i = 0; i < MAXV; ++i)
+      if (lane + i * 64 < nvec) {
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int v = lane + i * 64;
-    if (v < nvec) {
-      float y[EPV];
-#pragma unroll
-      for (int e = 0; e < EPV; ++e) {
-        const int c = v * EPV + e;
-        y[e] = (f[i][e] - mean) * rstd * gamma[c] + beta[c];
+        for (int e = 0; e < EPV; ++e) s[r] += f[r][i][e];
       }
-      store_vec<T>(out + (size_t)row * d + v * EPV, y);
+  float mean[R], q[R], rstd[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) mean[r] = wave_sum(s[r]) / (float)d;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    q[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (lane + i * 64 < nvec) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { const float t = f[r][i][e] - mean[r]; q[r] += t * t; }
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) rstd[r] = rsqrtf(wave_sum(q[r]) / (float)d + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < nvec) {
+      float g[EPV], b[EPV];
+#pragma unroll
+      for (int e = 0; e < EPV; e += 4) {
+        *reinterpret_cast<float4*>(g + e) = *reinterpret_cast<const float4*>(gamma + v * EPV + e);
+        *reinterpret_cast<float4*>(b + e) = *reinterpret_cast<const float4*>(beta + v * EPV + e);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (row0 + r < rows) {
+          float y[EPV];
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) y[e] = (f[r][i][e] - mean[r]) * rstd[r] * g[e] + b[e];
+          store_vec<T>(out + (size_t)(row0 + r) * d + v * EPV, y);
+        }
+      }
     }
   }
 }
@@ -304,12 +327,22 @@ int launch_ln(const void* x, void* out, const float* gamma, const float* beta, i
   SDMI_REQUIRE(x && out && gamma && beta, "layernorm: null pointer");
   SDMI_REQUIRE(d % EPV == 0 && d > 0 && rows > 0, "layernorm: d=%d must be a positive multiple of %d", d, EPV);
   const int nvec = d / EPV;
-  const dim3 grid((rows + 3) / 4), block(256);
-  ProfScope prof(PROF_LAYERNORM, stream, 0.0, 2.0 * rows * (double)d * sizeof(T));
-  if (nvec <= 64 * 3)
-    hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, stream, (const T*)x, (T*)out, gamma, beta, rows, d, eps);
+  char label[32];
+  snprintf(label, sizeof(label), "rows%d d%d", rows, d);
+  ProfScope prof(PROF_LAYERNORM, stream, 0.0, 2.0 * rows * (double)d * sizeof(T), label);
+  const dim3 block(256);
+  auto grid = [&](int r) { return dim3((rows + 4 * r - 1) / (4 * r)); };
+  // rows per wave: enough loads in flight for narrow rows, fewer when there are too few rows to fill the chip
+  if (nvec <= 64 && rows >= 16384)
+    hipLaunchKernelGGL((layernorm_kernel<T, 1, 4>), grid(4), block, 0, stream, (const T*)x, (T*)out, gamma, beta, rows, d, eps);
+  else if (nvec <= 64)
+    hipLaunchKernelGGL((layernorm_kernel<T, 1, 1>), grid(1), block, 0, stream, (const T*)x, (T*)out, gamma, beta, rows, d, eps);
+  else if (nvec <= 64 * 2 && rows >= 8192)
+    hipLaunchKernelGGL((layernorm_kernel<T, 2, 2>), grid(2), block, 0, stream, (const T*)x, (T*)out, gamma, beta, rows, d, eps);
+  else if (nvec <= 64 * 3)
+    hipLaunchKernelGGL((layernorm_kernel<T, 3, 1>), grid(1), block, 0, stream, (const T*)x, (T*)out, gamma, beta, rows, d, eps);
   else if (nvec <= 64 * 8)
-    hipLaunchKernelGGL((layernorm_kernel<T, 8>), grid, block, 0, stream, (const T*)x, (T*)out, gamma, beta, rows, d, eps);
+    hipLaunchKernelGGL((layernorm_kernel<T, 8, 1>), grid(1), block, 0, stream, (const T*)x, (T*)out, gamma, beta, rows, d, eps);
   else {
     sdmi_set_error("layernorm: d=%d too wide", d);
     return SDMI_EINVAL;

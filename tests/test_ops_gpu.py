@@ -116,7 +116,15 @@ def test_conv2d_tiles_256x160(ops, dt, case, monkeypatch):
 
 
 @pytest.mark.parametrize("dt", ["fp16", "bf16"])
-@pytest.mark.parametrize("shape", ["2", "3"])
+@pytest.mark.parametrize("case", PP_CASES, ids=[c[0] for c in PP_CASES])
+def test_conv2d_tiles_128x160(ops, dt, case, monkeypatch):
+    """Same cases through the 128 x 160 shape (two row fragments per wave)."""
+    monkeypatch.setenv("SDMI_GEMM_SHAPE", "4")
+    test_conv2d(ops, dt, case)
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("shape", ["2", "3", "4"])
 def test_large_tiles_long_k(ops, dt, shape, monkeypatch):
     """Many K-tiles across taps and both concat sources: ring wrap-around and segment changes."""
     monkeypatch.setenv("SDMI_GEMM_SHAPE", shape)
@@ -135,7 +143,7 @@ def test_large_tiles_epilogues(ops, dt, monkeypatch):
     res = q(rnd("ppepi.res", (B, Cout, H, W)), dt)
     ref = F.conv2d(x, w, b, padding=1) + emb[:, :, None, None] + res
     wp = ops.pack_weight(w.cuda(), dt)
-    for shape in ("2", "3"):
+    for shape in ("2", "3", "4"):
         monkeypatch.setenv("SDMI_GEMM_SHAPE", shape)
         for splits in (1, 2):
             y = ops.conv2d(nhwc(x, dt), wp, b.cuda(), taps=9, rowadd=emb.cuda(), resid=nhwc(res, dt), splits=splits)

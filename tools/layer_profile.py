@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch profile of one eager UNet forward (run on the GPU box):
-    python tools/layer_profile.py [batch] [out.csv]
+    python tools/layer_profile.py [vae] [cfg] [batch] [out.csv]
 Prints the launches grouped by (class, shape label), sorted by total time."""
 import collections, importlib, os, sys
 import torch
@@ -14,6 +14,9 @@ def main():
     vae = len(sys.argv) > 1 and sys.argv[1] == "vae"
     if vae:
         sys.argv.pop(1)
+    sampler_mode = len(sys.argv) > 1 and sys.argv[1] == "cfg"     # the promises DDIMSampler makes around its call
+    if sampler_mode:
+        sys.argv.pop(1)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", f"layers_{'vae_' if vae else ''}b{B}.csv")
     os.makedirs(os.path.dirname(out), exist_ok=True)
@@ -21,6 +24,9 @@ def main():
     model = pipeline.build_synthetic_model(4, "crossattn", "fp16")
     unet = model.model.diffusion_model
     unet.set_graph_mode(False)
+    if sampler_mode:
+        unet.set_uniform_timesteps(True)
+        unet.set_cfg_duplicate(True)
     x = pipeline.initial_latents(B, 64, 64)
     ctx = torch.cat(pipeline.synthetic_conditioning(B // 2)) if B >= 2 else pipeline.synthetic_conditioning(1)[0]
     t = torch.full((B,), 981, dtype=torch.int64, device="cuda")

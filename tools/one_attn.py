@@ -13,4 +13,11 @@ v = torch.randn(B, Nk, C, device="cuda").half()
 for _ in range(iters):
     y = ops.attention(q, k, v, 8)
 torch.cuda.synchronize()
-print("ok", float(y.float().abs().mean()))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters):
+    y = ops.attention(q, k, v, 8)
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / iters
+print(f"ok {float(y.float().abs().mean()):.5f}  {us:.1f} us/launch  {4.0 * B * 8 * N * Nk * d / us / 1e6:.1f} TF/s")

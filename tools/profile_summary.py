@@ -49,3 +49,84 @@ if fetch and write:
                          "--ddim-steps 4; KiB -> bytes; FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B)"},
               open(out, "w"), indent=1)
     print("wrote", out, f"fetch {fetch_b / 1e6:.1f} MB + write {write_b / 1e6:.1f} MB per launch")
+
+
+# ---- per kernel class: SQ issue/busy counters and HBM traffic of the normalisation kernels -----------------
+def classify(k):
+    if DOM in k:
+        return "conv_gemm 256x320"
+    if "conv_gemm_pp" in k:
+        return "conv_gemm other large tiles"
+    if "conv_gemm_kernel" in k:
+        return "conv_gemm 128x128"
+    if "attn_flash" in k:
+        return "attn_flash"
+    if "gn_partial" in k:
+        return "gn_partial"
+    if "gn_apply" in k:
+        return "gn_apply"
+    if "layernorm" in k:
+        return "layernorm"
+    return None
+
+
+def collect(dirname):
+    """class -> counter -> list of per-dispatch values (+ 'dur_us' once per dispatch)."""
+    out = {}
+    for f in glob.glob(os.path.join(ROOT, "gpurun_out", dirname, "*", "*counter_collection.csv")):
+        seen = set()
+        for r in csv.DictReader(open(f)):
+            c = classify(r["Kernel_Name"])
+            if c is None:
+                continue
+            d = out.setdefault(c, {})
+            d.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            if r["Dispatch_Id"] not in seen:
+                seen.add(r["Dispatch_Id"])
+                d.setdefault("dur_us", []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    return out
+
+
+mean = lambda v: sum(v) / len(v)
+sq = collect("pmc_sq")
+nf, nw = collect("pmc_norm_fetch"), collect("pmc_norm_write")
+summary = {"units": "per dispatch means over a 4-DDIM-step eager run of bench.py (UNet batch 16 + VAE decode); "
+                    "SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over the 1024 SIMDs (= 16 x the number of "
+                    "16x16x32 MFMAs, 32 x for 32x32x16); SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_ANY in "
+                    "quad-cycles summed over waves; FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled for gfx950",
+           "sq": {}, "hbm": {}}
+for c, d in sq.items():
+    waves_cyc = 4.0 * mean(d["SQ_WAVE_CYCLES"])
+    summary["sq"][c] = {
+        "dispatches": len(d["dur_us"]), "avg_duration_us": mean(d["dur_us"]),
+        "mfma_busy_cycles_per_simd": mean(d["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024.0,
+        "valu_active_cycles_per_simd": 4.0 * mean(d["SQ_ACTIVE_INST_VALU"]) / 1024.0,
+        "lds_active_cycles_per_simd": 4.0 * mean(d["SQ_ACTIVE_INST_LDS"]) / 1024.0,
+        "wave_cycles_per_simd": waves_cyc / 1024.0,
+        "wait_any_share_of_wave_cycles": mean(d["SQ_WAIT_ANY"]) / mean(d["SQ_WAVE_CYCLES"]),
+        "mfma_busy_share_of_wave_cycles": mean(d["SQ_VALU_MFMA_BUSY_CYCLES"]) / waves_cyc,
+        # SQ_BUSY_CYCLES is summed over the 32 shader engines (8 XCDs x 4): /32 = cycles the kernel kept them busy
+        "kernel_cycles": mean(d["SQ_BUSY_CYCLES"]) / 32.0,
+        "shader_clock_GHz": mean(d["SQ_BUSY_CYCLES"]) / 32.0 / mean(d["dur_us"]) / 1e3,
+        "mfma_pipe_busy_share": (mean(d["SQ_VALU_MFMA_BUSY_CYCLES"]) / 1024.0) / (mean(d["SQ_BUSY_CYCLES"]) / 32.0),
+        "valu_issue_share": (4.0 * mean(d["SQ_ACTIVE_INST_VALU"]) / 1024.0) / (mean(d["SQ_BUSY_CYCLES"]) / 32.0),
+        "valu_instructions": mean(d["SQ_INSTS_VALU"]),
+    }
+for c in nf:
+    if c not in nw:
+        continue
+    fb = 2.0 * 1024.0 * mean(nf[c]["FETCH_SIZE"])
+    wb = 1024.0 * mean(nw[c]["WRITE_SIZE"])
+    dur = mean(nf[c]["dur_us"] + nw[c]["dur_us"])
+    summary["hbm"][c] = {"dispatches": len(nf[c]["dur_us"]), "avg_duration_us": dur, "fetch_bytes": fb, "write_bytes": wb,
+                         "achieved_GBps": (fb + wb) / dur / 1e3, "peak_GBps": 8000.0}
+if summary["sq"] or summary["hbm"]:
+    out = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json")
+    json.dump(summary, open(out, "w"), indent=1)
+    print("wrote", out)
+    for c, v in summary["sq"].items():
+        print(f"  {c:30s} {v['avg_duration_us']:7.1f} us  MFMA pipe busy {100 * v['mfma_pipe_busy_share']:5.1f}% of kernel cycles "
+              f"at {v['shader_clock_GHz']:.2f} GHz, VALU issue {100 * v['valu_issue_share']:5.1f}%, waves waiting "
+              f"{100 * v['wait_any_share_of_wave_cycles']:5.1f}% of their cycles")
+    for c, v in summary["hbm"].items():
+        print(f"  {c:30s} {v['avg_duration_us']:7.1f} us  {v['achieved_GBps']:7.1f} GB/s")

@@ -147,9 +147,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnParams p) {
     for (int u = t; u < 8 * p.groups; u += (int)blockDim.x) {
       const int g = u % p.groups, slice = u / p.groups;
       double s = 0.0, q = 0.0;
-      for (int c = slice; c < p.chunks; c += 8) {
-        const float* src = p.partial + (((size_t)b * p.chunks + c) * p.groups + g) * 2;
-        s += (double)src[0]; q += (double)src[1];
+      const float2* src = reinterpret_cast<const float2*>(p.partial) + ((size_t)b * p.chunks * p.groups + g);
+      const size_t cstep = (size_t)p.groups;
+      int c = slice;
+      // four loads in flight; the sum keeps its fixed order
+      for (; c + 24 < p.chunks; c += 32) {
+        const float2 v0 = src[c * cstep], v1 = src[(c + 8) * cstep], v2 = src[(c + 16) * cstep], v3 = src[(c + 24) * cstep];
+        s += (double)v0.x; q += (double)v0.y;
+        s += (double)v1.x; q += (double)v1.y;
+        s += (double)v2.x; q += (double)v2.y;
+        s += (double)v3.x; q += (double)v3.y;
+      }
+      for (; c < p.chunks; c += 8) {
+        const float2 v = src[c * cstep];
+        s += (double)v.x; q += (double)v.y;
       }
       red[0][slice][g] = s; red[1][slice][g] = q;
     }
@@ -237,6 +248,10 @@ int launch_gn(const GroupNormArgs& a, hipStream_t stream) {
   const int max_by_work = (p.HW + 4 * lanes_pix - 1) / (4 * lanes_pix);
   if (chunks > max_by_work) chunks = max_by_work;
   if (chunks > GN_MAX_CHUNKS) chunks = GN_MAX_CHUNKS;
+  // every second-pass block folds its sample's chunk partials before it starts: with few samples a long
+  // list costs more (serial round trips) than the extra blocks gain
+  static const int chunk_cap = [] { const char* e = getenv("SDMI_GN_CHUNK_CAP"); return e ? atoi(e) : 64; }();
+  if (chunks > chunk_cap) chunks = chunk_cap;
   if (chunks < 1) chunks = 1;
   p.pix_per_chunk = (p.HW + chunks - 1) / chunks;
   p.chunks = (p.HW + p.pix_per_chunk - 1) / p.pix_per_chunk;

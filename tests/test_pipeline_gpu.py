@@ -116,6 +116,26 @@ def test_g7_c3_50_step_trajectory_psnr_fp16():
     assert p >= 35.0
 
 
+def test_full_size_vae_decode_batch8_against_golden():
+    """The benchmark's decode shape (8 latents of 64x64 -> 8 images of 512x512): the reference's final latent of
+    the 50-step trajectory, eight times; every decoded copy must match the reference's image (stored as fp16) and
+    the copies must agree with each other."""
+    model = device_latent_diffusion(4, "crossattn", "fp16")
+    ops = importlib.import_module("stable-diffusion_amd.ops")
+    g = golden("g7_c3_traj")
+    img = ops.to_image(model.decode_first_stage(g["z"].repeat(8, 1, 1, 1).cuda())).cpu()
+    assert tuple(img.shape) == (8, 3, 512, 512)
+    ref = g["image"].float()[0]
+    for i in range(8):
+        assert psnr(img[i], ref) >= 50.0, (i, psnr(img[i], ref))
+        assert max_rel_err(img[i], img[0]) < 1e-6
+    print(f"vae decode batch 8: PSNR vs reference image {psnr(img[0], ref):.1f} dB")
+    u8 = ops.to_image_u8(model.decode_first_stage(g["z"].repeat(2, 1, 1, 1).cuda())).cpu()
+    assert tuple(u8.shape) == (2, 512, 512, 3) and u8.dtype == torch.uint8
+    ref_u8 = (255.0 * ref.permute(1, 2, 0)).to(torch.uint8)
+    assert (u8[0].int() - ref_u8.int()).abs().max() <= 2        # reference image passed through fp16 storage
+
+
 @pytest.mark.parametrize("dt", ["fp32", "fp16"])
 def test_img2img_pipeline_against_oracle(dt):
     """pipeline.img2img (img2img.py:269-301: encode -> posterior sample -> stochastic_encode -> decode() with

@@ -111,6 +111,49 @@ def test_cfg_duplicate_promise(dt):
     net.set_graph_mode(True)
 
 
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_full_size_batch16_against_golden(dt):
+    """The benchmark's shape (UNet batch 16 at 64x64: the large-tile kernel plans, M = 65536 rows) checked
+    against the reference's batch-2 output: samples are independent, so eight copies of the golden pair must
+    each reproduce it, and the copies must agree with each other."""
+    net = device_unet(4, dt)
+    g = golden("g3_unet_c2")
+    x = g["x"].repeat(8, 1, 1, 1).cuda()
+    t = g["t"].repeat(8).cuda()
+    ctx = g["ctx"].float().repeat(8, 1, 1).cuda()
+    out = net(x, t, context=ctx).cpu().reshape(8, 2, 4, 64, 64)
+    for i in range(8):
+        err = max_rel_err(out[i], g["out"])
+        assert err < BAR[dt], (dt, i, err)
+    spread = max(max_rel_err(out[i], out[0]) for i in range(1, 8))
+    print(f"batch 16 {dt}: err vs golden {max_rel_err(out[0], g['out']):.3e}, spread between copies {spread:.3e}")
+    assert spread < 1e-6 if dt == "fp16" else spread < 1e-5
+
+
+def test_full_size_sampler_mode_against_golden():
+    """Same shape with the sampler's promises on (one timestep, CFG pairs share x): x = sample 0 of the golden
+    sixteen times, contexts [c0] * 8 + [c1] * 8; the first half must reproduce the golden output of (x0, c0),
+    and the whole batch the forward without promises."""
+    net = device_unet(4, "fp16")
+    g = golden("g3_unet_c2")
+    x = g["x"][:1].repeat(16, 1, 1, 1).cuda()
+    t = g["t"][:1].repeat(16).cuda()
+    c = g["ctx"].float()
+    ctx = torch.cat([c[:1].repeat(8, 1, 1), c[1:].repeat(8, 1, 1)]).cuda()
+    ref = net(x, t, context=ctx).clone()
+    net.set_uniform_timesteps(True)
+    net.set_cfg_duplicate(True)
+    try:
+        out = net(x, t, context=ctx).clone()
+    finally:
+        net.set_uniform_timesteps(False)
+        net.set_cfg_duplicate(False)
+    assert max_rel_err(out.cpu(), ref.cpu()) < 3e-3
+    for i in range(8):
+        assert max_rel_err(out[i].cpu(), g["out"][0]) < BAR["fp16"]
+    assert not torch.equal(out[0], out[8])
+
+
 def test_errors_are_loud():
     net = device_unet(4, "fp16")
     g = golden("g3_unet_c1")

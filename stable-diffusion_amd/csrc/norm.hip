@@ -197,18 +197,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnParams p) {
       sh[e] = p.beta[c + e] - s_mean[g] * rg;
     }
     int px = L.p_begin + L.pix_lane;
-    for (; px + L.lanes_pix < L.p_end; px += 2 * L.lanes_pix) {
-      float f0[EPV], f1[EPV];
-      load_vec<T>(src + (size_t)px * cs, f0);
-      load_vec<T>(src + (size_t)(px + L.lanes_pix) * cs, f1);
+    // four pixels per trip: four independent 16-byte loads in flight per thread
+    for (; px + 3 * L.lanes_pix < L.p_end; px += 4 * L.lanes_pix) {
+      float f[4][EPV];
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) {
-        f0[e] = fmaf(f0[e], sc[e], sh[e]);
-        f1[e] = fmaf(f1[e], sc[e], sh[e]);
-        if (p.silu) { f0[e] = silu_f(f0[e]); f1[e] = silu_f(f1[e]); }
+      for (int u = 0; u < 4; ++u) load_vec<T>(src + (size_t)(px + u * L.lanes_pix) * cs, f[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          f[u][e] = fmaf(f[u][e], sc[e], sh[e]);
+          if (p.silu) f[u][e] = silu_f(f[u][e]);
+        }
+        store_vec<T>(dst + (size_t)(px + u * L.lanes_pix) * p.C, f[u]);
       }
-      store_vec<T>(dst + (size_t)px * p.C, f0);
-      store_vec<T>(dst + (size_t)(px + L.lanes_pix) * p.C, f1);
     }
     for (; px < L.p_end; px += L.lanes_pix) {
       float f[EPV];

@@ -300,6 +300,54 @@ class LatentDiffusion:
         return img
 
     @torch.no_grad()
+    def progressive_denoising(self, cond, shape, verbose=True, callback=None, quantize_denoised=False,
+                              img_callback=None, mask=None, x0=None, temperature=1., noise_dropout=0.,
+                              score_corrector=None, corrector_kwargs=None, batch_size=None, x_T=None, start_T=None,
+                              log_every_t=None):
+        """stable_diffusion.py:4723-4777: the ancestral loop that also collects the x0 predictions."""
+        if not log_every_t:
+            log_every_t = self.log_every_t
+        timesteps = self.num_timesteps
+        if batch_size is not None:
+            b = batch_size
+            shape = [batch_size] + list(shape)
+        else:
+            b = batch_size = shape[0]
+        img = torch.randn(shape, device=self.device) if x_T is None else x_T.to(self.device, torch.float32)
+        intermediates = []
+        if cond is not None:
+            if isinstance(cond, dict):
+                cond = {key: cond[key][:batch_size] if not isinstance(cond[key], list) else
+                        [x[:batch_size] for x in cond[key]] for key in cond}
+            else:
+                cond = [c[:batch_size] for c in cond] if isinstance(cond, list) else cond[:batch_size]
+        if start_T is not None:
+            timesteps = min(timesteps, start_T)
+        if type(temperature) == float:
+            temperature = [temperature] * timesteps
+        self.model.diffusion_model.set_uniform_timesteps(True)
+        try:
+            for i in reversed(range(0, timesteps)):
+                ts = torch.full((b,), i, device=self.device, dtype=torch.long)
+                img, x0_partial = self.p_sample(img, cond, ts, clip_denoised=self.clip_denoised,
+                                                quantize_denoised=quantize_denoised, return_x0=True,
+                                                temperature=temperature[i], noise_dropout=noise_dropout,
+                                                score_corrector=score_corrector, corrector_kwargs=corrector_kwargs)
+                if mask is not None:
+                    assert x0 is not None
+                    img_orig = self.q_sample(x0, ts)
+                    img = img_orig * mask + (1. - mask) * img
+                if i % log_every_t == 0 or i == timesteps - 1:
+                    intermediates.append(x0_partial)
+                if callback:
+                    callback(i)
+                if img_callback:
+                    img_callback(img, i)
+        finally:
+            self.model.diffusion_model.set_uniform_timesteps(False)
+        return img, intermediates
+
+    @torch.no_grad()
     def sample(self, cond, batch_size=16, return_intermediates=False, x_T=None, verbose=True, timesteps=None,
                quantize_denoised=False, mask=None, x0=None, shape=None, **kwargs):
         """stable_diffusion.py:4832-4847."""

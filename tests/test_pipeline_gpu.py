@@ -272,6 +272,10 @@ def test_ddpm_p_sample_and_loop_against_oracle():
         img, _ = sampler_ref.ddpm_update(img.cpu(), eps.cpu(), t, tab, n.cpu())
         img = img.cuda()
     assert max_rel_err(out.cpu(), img.cpu()) < 1e-5
+    # progressive_denoising: same loop, collects the x0 predictions; same RNG stream -> same result
+    torch.manual_seed(3)
+    out2, x0s = model.progressive_denoising(ctx, tuple(x.shape), x_T=x, start_T=3, log_every_t=1, verbose=False)
+    assert torch.equal(out2, out) and len(x0s) == 3 and x0s[0].shape == x.shape
 
 
 @pytest.mark.parametrize("dt", ["fp32", "fp16", "bf16"])

@@ -62,7 +62,13 @@ template <int D> struct Geo {
   static constexpr int CPR = D / 8;                       // 16-byte chunks per K/V row
   static constexpr int NCH = KV_TILE * CPR;               // chunks per tile
   static constexpr int KC = (NCH + 255) / 256;            // chunks per thread
-  static constexpr int SK = ((D * 2 + 15) / 16 * 16) | 16;    // K row stride: odd multiple of 16 B
+  // Head sizes that leave spare contraction slots in the last 16-wide step (D % 16 == 8: 40) carry the
+  // running maximum through the matrix cores: K rows get two extra columns holding 1, the query fragment
+  // the two halves (hi, lo) of -m, and Q is scaled by scale * log2(e) when it is loaded, so that the
+  // accumulators come out as the exponent itself (no multiply-subtract per score).
+  static constexpr bool FOLD = (D % 16) == 8;
+  static constexpr int SK = FOLD ? ((KSTEPS * 32) | 16)                 // room for the extra columns
+                                 : (((D * 2 + 15) / 16 * 16) | 16);     // K row stride: odd multiple of 16 B
   static constexpr int sv_min = DT * 64;                  // bytes the transpose reads touch per row
   static constexpr int SV = (sv_min <= 64) ? 64 : (sv_min <= 192 ? 192 : (sv_min <= 320 ? 320 : (sv_min <= 448 ? 448 : 576)));
   static constexpr int KBUF = KV_TILE * SK + 32;          // + zeroed tail for the last row's over-read
@@ -72,7 +78,7 @@ template <int D> struct Geo {
 };
 
 template <typename T, int D>
-__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_flash_kernel(FlashParams p) {
+__global__ __launch_bounds__(256, (D <= 40 ? 4 : (D <= 80 ? 2 : 1))) void attn_flash_kernel(FlashParams p) {
   typedef Geo<D> G;
   typedef typename Mfma32<T>::v8 v8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -89,8 +95,13 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_flash_kernel(Flas
 #pragma unroll
     for (int s = 0; s < G::KSTEPS; ++s) {
       const int d0 = 16 * s + 8 * h;
-      if (d0 < D) qf[s] = *reinterpret_cast<const v8*>(qp + d0 * sizeof(T));
-      else {
+      if (d0 < D) {
+        qf[s] = *reinterpret_cast<const v8*>(qp + d0 * sizeof(T));
+        if constexpr (G::FOLD) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) qf[s][e] = (T)((float)qf[s][e] * p.c);
+        }
+      } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) qf[s][e] = (T)0.f;
       }
@@ -133,6 +144,15 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_flash_kernel(Flas
   if (tid < 4) {
     const int buf = tid >> 1, part = tid & 1;
     *reinterpret_cast<u32x4*>(smem + buf * G::STAGE + KV_TILE * G::SK + part * 16) = (u32x4){0u, 0u, 0u, 0u};
+  }
+  if constexpr (G::FOLD) {
+    // columns D, D+1 of every K row = 1 (they meet the (hi, lo) halves of -m in the query fragment), the
+    // other spare columns 0; the staging never writes there
+    if (tid < 2 * KV_TILE) {
+      T* krow = reinterpret_cast<T*>(smem + (tid >> 6) * G::STAGE + (tid & 63) * G::SK + D * 2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) krow[e] = (T)(e < 2 ? 1.f : 0.f);
+    }
   }
   // Head sizes with spare columns in the last 32-wide output tile: V column D is set to 1 in both
   // buffers (the staging never writes there), so output row D accumulates the softmax denominator on
@@ -207,27 +227,60 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_flash_kernel(Flas
     for (int i = 3; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s0[i]), s0[i + 1 < 16 ? i + 1 : i]);
 #pragma unroll
     for (int i = 2; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s1[i]), s1[i + 1]);
-    mx *= p.c;
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    if (__any(mx > m_run + 8.0f)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < G::DT; ++dt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
-    }
-    const float m_new = m_run;
     v8 pf[4];        // P^T fragments: block 0 k-steps 0,1 then block 1 k-steps 0,1
+    if constexpr (G::FOLD) {
+      // the accumulators already hold score * c - m_run
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (t == 0 || __any(mx > 8.0f)) {
+        // first tile: adopt the row maximum; later: move up by the overshoot
+        const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+        if (t != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          l_run *= alpha;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float e0 = __builtin_amdgcn_exp2f(fmaf(s0[i], p.c, -m_new));
-      const float e1 = __builtin_amdgcn_exp2f(fmaf(s1[i], p.c, -m_new));
-      if constexpr (!G::ONES) l_run += e0 + e1;
-      pf[i >> 3][i & 7] = (T)e0;
-      pf[2 + (i >> 3)][i & 7] = (T)e1;
+          for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+        }
+        m_run = (t == 0 ? 0.f : m_run) + delta;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] -= delta; s1[i] -= delta; }
+        if (h == 1) {
+          const T hi = (T)(-m_run);
+          const T lo = (T)(-m_run - (float)hi);
+          qf[G::KSTEPS - 1][0] = hi;
+          qf[G::KSTEPS - 1][1] = lo;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float e0 = __builtin_amdgcn_exp2f(s0[i]);
+        const float e1 = __builtin_amdgcn_exp2f(s1[i]);
+        pf[i >> 3][i & 7] = (T)e0;
+        pf[2 + (i >> 3)][i & 7] = (T)e1;
+      }
+    } else {
+      mx *= p.c;
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (__any(mx > m_run + 8.0f)) {
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+      }
+      const float m_new = m_run;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float e0 = __builtin_amdgcn_exp2f(fmaf(s0[i], p.c, -m_new));
+        const float e1 = __builtin_amdgcn_exp2f(fmaf(s1[i], p.c, -m_new));
+        if constexpr (!G::ONES) l_run += e0 + e1;
+        pf[i >> 3][i & 7] = (T)e0;
+        pf[2 + (i >> 3)][i & 7] = (T)e1;
+      }
     }
 
     // ---- O^T += V^T P^T ---------------------------------------------------------------------------
@@ -282,6 +335,7 @@ template <typename T, int D>
 int launch_flash(const AttentionArgs& a, hipStream_t stream) {
   typedef Geo<D> G;
   static_assert(D % 8 == 0 && G::DT * 64 <= G::SV && D * 2 <= G::SV, "bad head size geometry");
+  static_assert(!G::FOLD || (G::ONES && G::KSTEPS * 32 <= G::SK), "folded maximum needs spare K and V columns");
   FlashParams p;
   p.q = (const char*)a.q; p.k = (const char*)a.k; p.v = (const char*)a.v; p.out = (char*)a.out;
   p.ldq = a.ldq; p.ldk = a.ldk; p.ldv = a.ldv; p.ldo = a.ldo;

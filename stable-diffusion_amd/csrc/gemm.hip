@@ -59,7 +59,6 @@ struct GemmParams {
   const char* zero;   // 256 zero bytes (halo / out-of-range rows read these)
   int dup_rows;       // > 0: rows are stored a second time dup_rows further down
   int wide_store;     // large-tile kernel: 16-bit output written through the LDS strips
-  int dbg;   // timing experiments only: bit0 = activation loads hit the zero page, bit1 = weight loads
 };
 
 template <typename T> struct Frag;      // 16 bytes of T as an MFMA operand fragment
@@ -247,7 +246,7 @@ __device__ __forceinline__ void store_wave_tile_lds(const GemmParams& p, f32x4 (
       Tout o;
 #pragma unroll
       for (int e = 0; e < EPC; ++e) o[e] = from_f32<OutT>(v[e]);
-      if (lane + 64 * k < TOTAL && m < p.M && (!(p.dbg & 32) || v[0] == 12345.678f)) {
+      if (lane + 64 * k < TOTAL && m < p.M) {
         *reinterpret_cast<Tout*>(out + (size_t)m * ldo + n_out + c_col[k]) = o;
         if (p.dup_rows > 0) *reinterpret_cast<Tout*>(out + (size_t)(m + p.dup_rows) * ldo + n_out + c_col[k]) = o;
       }
@@ -306,7 +305,7 @@ __global__ __launch_bounds__(S::NTHREADS) void conv_gemm_kernel(GemmParams p) {
 #pragma unroll
   for (int i = 0; i < WP; ++i) {
     const int n = n0 + (wid * WP + i) * 8 + lrow;
-    const bool wok = n < p.N && !(p.dbg & 2);
+    const bool wok = n < p.N;
     wptr[i] = wok ? p.w + ((size_t)n * p.K) * sizeof(T) + sc * 16 : p.zero + sc * 16;
     wstep[i] = wok ? 128 : 0;
   }
@@ -338,7 +337,6 @@ __global__ __launch_bounds__(S::NTHREADS) void conv_gemm_kernel(GemmParams p) {
         if (p.up) { iy >>= 1; ix >>= 1; }
         pix = ((size_t)a_b[i] * p.Hin + iy) * p.Win + ix;
       }
-      if (p.dbg & 1) ok = false;
       acur[i] = ok ? base + (pix * cs + (size_t)cseg * BK) * sizeof(T) + sc * 16 : zero;
       astep[i] = ok ? 128 : 0;
     }
@@ -353,14 +351,12 @@ __global__ __launch_bounds__(S::NTHREADS) void conv_gemm_kernel(GemmParams p) {
 
   // issue the DMA of the cursor's tile into stage `buf`, then advance the cursor
   auto prefetch = [&](int buf) {
-    if (!(p.dbg & 4)) {
-      char* abuf = smem + buf * S::STAGE_BYTES;
-      char* wbuf = abuf + S::A_BYTES;
+    char* abuf = smem + buf * S::STAGE_BYTES;
+    char* wbuf = abuf + S::A_BYTES;
 #pragma unroll
-      for (int i = 0; i < AP; ++i) glds16(acur[i], abuf + (wid * AP + i) * 1024);
+    for (int i = 0; i < AP; ++i) glds16(acur[i], abuf + (wid * AP + i) * 1024);
 #pragma unroll
-      for (int i = 0; i < WP; ++i) glds16(wptr[i], wbuf + (wid * WP + i) * 1024);
-    }
+    for (int i = 0; i < WP; ++i) glds16(wptr[i], wbuf + (wid * WP + i) * 1024);
 #pragma unroll
     for (int i = 0; i < AP; ++i) acur[i] += astep[i];
 #pragma unroll
@@ -665,13 +661,6 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
 
-  if (p.dbg & 8) {      // timing experiments: no epilogue (accumulators kept alive)
-#pragma unroll
-    for (int i = 0; i < NFW; ++i)
-#pragma unroll
-      for (int j = 0; j < MJ; ++j) asm volatile("" ::"v"(acc[i][j]));
-    return;
-  }
   GemmParams pe = p;
   if (own_epilogue) { pe.bias = nullptr; pe.rowadd = nullptr; }      // already in the accumulators
   const int m_wave = m0 + wr * WROWS, n_wave = n0 + grp * (S::BN / 2);
@@ -780,6 +769,12 @@ struct Plan { int kind, splits; };
 int forced_kind() {
   const char* e = getenv("SDMI_GEMM_SHAPE");
   return e ? atoi(e) : 0;
+}
+// SDMI_GEMM_DIRECT_STORE=1 (tests; read on every call): large-tile kernels store straight from the
+// accumulator layout, the path otherwise taken only for outputs that are not 16-byte addressable
+bool direct_store_forced() {
+  const char* e = getenv("SDMI_GEMM_DIRECT_STORE");
+  return e && atoi(e) != 0;
 }
 
 constexpr double T_KT_SMALL_US = 1.40;    // 128x128x64 K-tile, two blocks per CU
@@ -896,15 +891,11 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   p.partial = splits > 1 ? a.partial : nullptr;
   SDMI_REQUIRE(splits == 1 || a.partial, "conv_gemm: split-K needs a partial buffer");
   SDMI_TRY(conv_gemm_init());
-  {
-    static const int dbg = [] { const char* e = getenv("SDMI_GEMM_DEBUG_ZERO"); return e ? atoi(e) : 0; }();
-    p.dbg = dbg;
-  }
   p.zero = g_zero_page;
   const int kind = pick_kind(p.M, p.N, p.K, a.dtype, a.geglu != 0);
   p.wide_store = a.ldo % 8 == 0 && (!a.resid || a.ldr % 8 == 0) && ((uintptr_t)a.out % 16 == 0) &&
                  (!a.resid || (uintptr_t)a.resid % 16 == 0) && (!p.partial || (uintptr_t)p.partial % 16 == 0) &&
-                 !(p.out_f32 && p.geglu) && !(p.dbg & 16);
+                 !(p.out_f32 && p.geglu) && !direct_store_forced();
   {
     char label[64];
     snprintf(label, sizeof(label), "M%d N%d K%d t%d s%d u%d g%d x%d k%d", p.M, p.N, p.K, p.taps, p.stride, p.up,

@@ -125,6 +125,16 @@ def test_conv2d_tiles_128x160(ops, dt, case, monkeypatch):
 
 @pytest.mark.parametrize("dt", ["fp16", "bf16"])
 @pytest.mark.parametrize("shape", ["2", "3", "4"])
+def test_large_tiles_direct_store_path(ops, dt, shape, monkeypatch):
+    """The store path for outputs that are not 16-byte addressable (straight from the accumulator layout)."""
+    monkeypatch.setenv("SDMI_GEMM_SHAPE", shape)
+    monkeypatch.setenv("SDMI_GEMM_DIRECT_STORE", "1")
+    for case in PP_CASES[:4]:
+        test_conv2d(ops, dt, case)
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("shape", ["2", "3", "4"])
 def test_large_tiles_long_k(ops, dt, shape, monkeypatch):
     """Many K-tiles across taps and both concat sources: ring wrap-around and segment changes."""
     monkeypatch.setenv("SDMI_GEMM_SHAPE", shape)

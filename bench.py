@@ -66,7 +66,7 @@ def prof_read(lib, name):
 
 
 DOMINANT_KIND = "k1"          # label suffix of the 256x320 large-tile GEMM launches in the profiler dump
-DOMINANT_NAME = "conv_gemm_pp_kernel<half, PPShape<10,2,2>> (256x320 implicit-GEMM conv3x3/conv1x1/linear)"
+DOMINANT_NAME = "conv_gemm_pp_kernel<{elem}, PPShape<10,2,2>> (256x320 implicit-GEMM conv3x3/conv1x1/linear)"
 
 
 def prof_dump_by_label(lib):
@@ -258,7 +258,7 @@ def main():
         dom_us = max(raw_us - cal.value * len(dom), 1e-9)
         achieved = dom_fl / (dom_us * 1e-6) / 1e12 if dom else 0.0
         result["roofline"] = {
-            "bound": "mfma", "kernel": DOMINANT_NAME,
+            "bound": "mfma", "kernel": DOMINANT_NAME.format(elem={"fp16": "half", "bf16": "bfloat16"}.get(args.dtype, "float")),
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic(),
             "launches": len(dom), "avg_launch_us": dom_us / max(1, len(dom)),
             "flops_per_launch": dom_fl / max(1, len(dom)), "kernel_ms_per_step": dom_us * 1e-3,

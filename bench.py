@@ -140,16 +140,32 @@ def cpu_baseline(ddim_steps, size, with_clip=True):
             "unet_it_per_s_batch2": 1.0 / t_unet}
 
 
+_T0 = time.perf_counter()
+
+
+def log(rank, msg):
+    """Progress on stderr (stdout carries the one JSON line)."""
+    print(f"[bench rank {rank} +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    # rehearsal knobs for a box with fewer GPUs than ranks: SDMI_BENCH_BACKEND=gloo (no RCCL between ranks that
+    # share a device) and SDMI_BENCH_SHARE_DEVICE=1 (every rank on cuda:0); the driver's runs use neither
+    backend = os.environ.get("SDMI_BENCH_BACKEND", "nccl")
+    if os.environ.get("SDMI_BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -159,7 +175,9 @@ def main():
     _lib = importlib.import_module("stable-diffusion_amd._lib")
     lib = _lib.lib()
 
+    log(rank, f"world {world}, device {dev}, building the model")
     model = pipeline.build_synthetic_model(4, "crossattn", args.dtype, device=dev, text_encoder=not args.no_clip)
+    log(rank, "model built")
     unet = model.model.diffusion_model
     if args.no_graph:
         unet.set_graph_mode(False)
@@ -172,9 +190,12 @@ def main():
         uc, c = pipeline.synthetic_prompt_tokens(B, dev, first_sample=first)
     x_T = pipeline.initial_latents(B, h, h, dev, first_sample=first)
 
-    def step():
+    def local_step():
         img, _ = pipeline.txt2img(model, x_T, uc, c, steps=args.ddim_steps, scale=args.scale, sampler=sampler)
-        return pipeline.gather_images(img)
+        return img
+
+    def step():
+        return pipeline.gather_images(local_step())
 
     def fence():
         torch.cuda.synchronize()
@@ -185,13 +206,15 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    log(rank, f"{args.warmup} warmup step(s) done, timing {args.steps}")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     fence()
     elapsed = time.perf_counter() - t0
+    log(rank, f"timed region {elapsed:.3f} s")
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert out.shape[0] == world * B and bool(torch.isfinite(out).all())
@@ -237,11 +260,12 @@ def main():
             result["step_tflops"] = step_tflop / (elapsed / args.steps)
 
     if rank == 0 and not args.no_roofline:
+        log(rank, "roofline pass")
         # ---- roofline of the dominant kernel: one extra eager pass of the same step under HIP events ----
         unet.set_graph_mode(False)
         lib.sdmi_prof_reset()
         lib.sdmi_prof_enable(1)
-        step()
+        local_step()              # rank 0 alone: no collective in this pass
         torch.cuda.synchronize()
         lib.sdmi_prof_enable(0)
         gemm = prof_read(lib, "conv_gemm")
@@ -277,8 +301,10 @@ def main():
             result[k + "_GBps"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else None
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log(rank, "CPU baseline (about a minute of host work)")
         result["cpu_baseline"] = cpu_baseline(args.ddim_steps, args.size, with_clip=not args.no_clip)
 
+    log(rank, "done")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -142,6 +142,10 @@ def gather_images(img, world=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return img
     world = dist.get_world_size()
+    if img.is_cuda and dist.get_backend() == "gloo":
+        # gloo has no all-gather on device tensors: stage through the host (CPU rehearsals of the multi-rank path)
+        host = gather_images(img.cpu(), world)
+        return host.to(img.device)
     out = torch.empty((world * img.shape[0],) + tuple(img.shape[1:]), dtype=img.dtype, device=img.device)
     try:
         dist.all_gather_into_tensor(out, img.contiguous())

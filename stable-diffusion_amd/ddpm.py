@@ -261,91 +261,78 @@ class LatentDiffusion:
         x_prev, x0 = self._ddpm_update(x, model_out.contiguous(), tt, clip_denoised, noise, temperature, return_x0)
         return (x_prev, x0) if return_x0 else x_prev
 
-    @torch.no_grad()
-    def p_sample_loop(self, cond, shape, return_intermediates=False, x_T=None, verbose=True, callback=None,
-                      timesteps=None, quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None,
-                      log_every_t=None):
-        """stable_diffusion.py:4780-4829."""
-        if not log_every_t:
-            log_every_t = self.log_every_t
-        b = shape[0]
-        img = torch.randn(shape, device=self.device) if x_T is None else x_T.to(self.device, torch.float32)
-        intermediates = [img]
-        if timesteps is None:
-            timesteps = self.num_timesteps
-        if mask is not None:
-            assert x0 is not None
-            assert x0.shape[2:3] == mask.shape[2:3]
-        if start_T is not None:
-            timesteps = min(timesteps, start_T)
-        self.model.diffusion_model.set_uniform_timesteps(True)
+    @staticmethod
+    def _first_n(cond, n):
+        """The leading n conditioning entries, through the dict / list nesting the scripts use (:4742-4746)."""
+        if cond is None:
+            return None
+        cut = lambda v: [e[:n] for e in v] if isinstance(v, list) else v[:n]
+        return {k: cut(v) for k, v in cond.items()} if isinstance(cond, dict) else cut(cond)
+
+    def _ancestral_loop(self, cond, img, steps, step_fn, keep, log_every_t, mask, x0, callback, img_callback):
+        """Shared body of p_sample_loop / progressive_denoising: t = steps-1 .. 0, one UNet call and one fused
+        update per step (``step_fn`` returns the new latent and what to log), optional known-region blend."""
+        b = img.shape[0]
+        unet = self.model.diffusion_model
+        unet.set_uniform_timesteps(True)          # one timestep for the whole batch in every call below
         try:
-            for i in reversed(range(0, timesteps)):
+            for i in range(steps - 1, -1, -1):
                 ts = torch.full((b,), i, device=self.device, dtype=torch.long)
-                img = self.p_sample(img, cond, ts, clip_denoised=self.clip_denoised,
-                                    quantize_denoised=quantize_denoised)
+                img, logged = step_fn(img, cond, ts, i)
                 if mask is not None:
-                    img_orig = self.q_sample(x0, ts)
-                    img = img_orig * mask + (1. - mask) * img
-                if i % log_every_t == 0 or i == timesteps - 1:
-                    intermediates.append(img)
+                    img = self.q_sample(x0, ts) * mask + (1. - mask) * img
+                if i % log_every_t == 0 or i == steps - 1:
+                    keep.append(logged if logged is not None else img)
                 if callback:
                     callback(i)
                 if img_callback:
                     img_callback(img, i)
         finally:
-            self.model.diffusion_model.set_uniform_timesteps(False)
-        if return_intermediates:
-            return img, intermediates
+            unet.set_uniform_timesteps(False)
         return img
+
+    @torch.no_grad()
+    def p_sample_loop(self, cond, shape, return_intermediates=False, x_T=None, verbose=True, callback=None,
+                      timesteps=None, quantize_denoised=False, mask=None, x0=None, img_callback=None, start_T=None,
+                      log_every_t=None):
+        """stable_diffusion.py:4780-4829: ancestral sampling from x_T (or fresh noise) down to t = 0."""
+        img = torch.randn(shape, device=self.device) if x_T is None else x_T.to(self.device, torch.float32)
+        steps = self.num_timesteps if timesteps is None else timesteps
+        if start_T is not None:
+            steps = min(steps, start_T)
+        if mask is not None:
+            assert x0 is not None
+            assert x0.shape[2:3] == mask.shape[2:3]  # spatial size has to match
+        intermediates = [img]
+        step = lambda im, c, ts, i: (self.p_sample(im, c, ts, clip_denoised=self.clip_denoised,
+                                                   quantize_denoised=quantize_denoised), None)
+        img = self._ancestral_loop(cond, img, steps, step, intermediates, log_every_t or self.log_every_t, mask, x0,
+                                   callback, img_callback)
+        return (img, intermediates) if return_intermediates else img
 
     @torch.no_grad()
     def progressive_denoising(self, cond, shape, verbose=True, callback=None, quantize_denoised=False,
                               img_callback=None, mask=None, x0=None, temperature=1., noise_dropout=0.,
                               score_corrector=None, corrector_kwargs=None, batch_size=None, x_T=None, start_T=None,
                               log_every_t=None):
-        """stable_diffusion.py:4723-4777: the ancestral loop that also collects the x0 predictions."""
-        if not log_every_t:
-            log_every_t = self.log_every_t
-        timesteps = self.num_timesteps
+        """stable_diffusion.py:4723-4777: the same loop, logging the x0 predictions; ``shape`` excludes the batch
+        axis when ``batch_size`` is given."""
         if batch_size is not None:
-            b = batch_size
             shape = [batch_size] + list(shape)
-        else:
-            b = batch_size = shape[0]
+        b = shape[0]
         img = torch.randn(shape, device=self.device) if x_T is None else x_T.to(self.device, torch.float32)
-        intermediates = []
-        if cond is not None:
-            if isinstance(cond, dict):
-                cond = {key: cond[key][:batch_size] if not isinstance(cond[key], list) else
-                        [x[:batch_size] for x in cond[key]] for key in cond}
-            else:
-                cond = [c[:batch_size] for c in cond] if isinstance(cond, list) else cond[:batch_size]
-        if start_T is not None:
-            timesteps = min(timesteps, start_T)
-        if type(temperature) == float:
-            temperature = [temperature] * timesteps
-        self.model.diffusion_model.set_uniform_timesteps(True)
-        try:
-            for i in reversed(range(0, timesteps)):
-                ts = torch.full((b,), i, device=self.device, dtype=torch.long)
-                img, x0_partial = self.p_sample(img, cond, ts, clip_denoised=self.clip_denoised,
-                                                quantize_denoised=quantize_denoised, return_x0=True,
-                                                temperature=temperature[i], noise_dropout=noise_dropout,
-                                                score_corrector=score_corrector, corrector_kwargs=corrector_kwargs)
-                if mask is not None:
-                    assert x0 is not None
-                    img_orig = self.q_sample(x0, ts)
-                    img = img_orig * mask + (1. - mask) * img
-                if i % log_every_t == 0 or i == timesteps - 1:
-                    intermediates.append(x0_partial)
-                if callback:
-                    callback(i)
-                if img_callback:
-                    img_callback(img, i)
-        finally:
-            self.model.diffusion_model.set_uniform_timesteps(False)
-        return img, intermediates
+        steps = self.num_timesteps if start_T is None else min(self.num_timesteps, start_T)
+        temps = [temperature] * steps if isinstance(temperature, float) else temperature
+        if mask is not None:
+            assert x0 is not None
+        x0_log = []
+        step = lambda im, c, ts, i: self.p_sample(im, c, ts, clip_denoised=self.clip_denoised,
+                                                  quantize_denoised=quantize_denoised, return_x0=True,
+                                                  temperature=temps[i], noise_dropout=noise_dropout,
+                                                  score_corrector=score_corrector, corrector_kwargs=corrector_kwargs)
+        img = self._ancestral_loop(self._first_n(cond, b), img, steps, step, x0_log, log_every_t or self.log_every_t,
+                                   mask, x0, callback, img_callback)
+        return img, x0_log
 
     @torch.no_grad()
     def sample(self, cond, batch_size=16, return_intermediates=False, x_T=None, verbose=True, timesteps=None,
@@ -353,11 +340,6 @@ class LatentDiffusion:
         """stable_diffusion.py:4832-4847."""
         if shape is None:
             shape = (batch_size, self.channels, self.image_size, self.image_size)
-        if cond is not None:
-            if isinstance(cond, dict):
-                cond = {key: cond[key][:batch_size] if not isinstance(cond[key], list) else
-                        [x[:batch_size] for x in cond[key]] for key in cond}
-            else:
-                cond = [c[:batch_size] for c in cond] if isinstance(cond, list) else cond[:batch_size]
-        return self.p_sample_loop(cond, shape, return_intermediates=return_intermediates, x_T=x_T, verbose=verbose,
-                                  timesteps=timesteps, quantize_denoised=quantize_denoised, mask=mask, x0=x0)
+        return self.p_sample_loop(self._first_n(cond, batch_size), shape, return_intermediates=return_intermediates,
+                                  x_T=x_T, verbose=verbose, timesteps=timesteps, quantize_denoised=quantize_denoised,
+                                  mask=mask, x0=x0)

@@ -17,15 +17,16 @@ from . import ops
 
 
 def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
-    """stable_diffusion.py:5141-5153."""
+    """stable_diffusion.py:5141-5153: every (T // S)-th step ("uniform") or quadratically spaced steps up to
+    0.8 T ("quad"), shifted by one so that the last entry reaches the end of the training schedule."""
+    T, S = num_ddpm_timesteps, num_ddim_timesteps
     if ddim_discr_method == "uniform":
-        c = num_ddpm_timesteps // num_ddim_timesteps
-        ddim_timesteps = np.asarray(list(range(0, num_ddpm_timesteps, c)))
+        base = np.arange(0, T, T // S, dtype=np.int64)
     elif ddim_discr_method == "quad":
-        ddim_timesteps = ((np.linspace(0, np.sqrt(num_ddpm_timesteps * 0.8), num_ddim_timesteps)) ** 2).astype(int)
+        base = np.square(np.linspace(0, np.sqrt(0.8 * T), S)).astype(int)
     else:
         raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
-    steps_out = ddim_timesteps + 1
+    steps_out = base + 1
     if verbose:
         print(f"Selected timesteps for ddim sampler: {steps_out}")
     return steps_out

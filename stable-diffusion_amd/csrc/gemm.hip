@@ -463,7 +463,7 @@ typedef PPShape<8, 2, 2> PP256;
 typedef PPShape<5, 1, 3> PP160;
 typedef PPShape<5, 1, 3, 2> PP160H;     // 128x160: layers whose 256-row tiles would leave CUs idle
 
-template <typename T, typename S>
+template <typename T, typename S, bool TI>
 __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit operands only");
   constexpr int BK = 64, AP = S::AP, NFW = S::NFW, NFP = S::NFP, NPH = S::NPH, NSTAGE = S::NSTAGE, MJ = S::MJ;
@@ -491,8 +491,16 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   const int sc = (lane & 7) ^ lrow;
   const int hw = p.Ho * p.Wo;
   const bool pointwise = (p.taps == 1 && p.stride == 1 && !p.up);
-  // per row: sample index (-1 = row beyond M) and the output pixel packed as (oy << 16 | ox); for
-  // pointwise problems the pixel is the row index itself
+  // Two K orders.  3x3 convolutions without upsampling walk the nine taps of a 64-channel slice in
+  // consecutive K-tiles (kt = slice * 9 + tap): the shifted views of the same activation rows are then
+  // fetched back to back and meet in L2 (the 32 workgroups of an XCD touch about 1 MB per K-tile; a
+  // tap-major walk puts 5 MB between two views and every tap goes out to the fabric again).  Pointwise
+  // problems and upsampling convolutions keep the tap-major walk (kt = tap * slices + slice).
+  constexpr bool tapinner = TI;       // the launcher picks TI only for taps == 9 without upsampling
+  // per row, tap-major walk: sample index (-1 = row beyond M) and the output pixel packed as
+  // (oy << 16 | ox), for pointwise problems the row index itself; tap-inner walk: bit mask of the taps
+  // that fall inside the image (0 = row beyond M) and the linear index of the centre input pixel, the
+  // one tap (pad, pad) reads
   int a_b[AP], a_px[AP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
@@ -503,8 +511,24 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
       a_b[i] = ok ? 0 : -1; a_px[i] = mm;
     } else {
       const int b = mm / hw, rem = mm - b * hw;
-      const int oy = rem / p.Wo;
-      a_b[i] = ok ? b : -1; a_px[i] = (oy << 16) | (rem - oy * p.Wo);
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      if constexpr (tapinner) {
+        const int cy = oy * p.stride, cx = ox * p.stride;
+        unsigned my = 0, mx = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          if (cy + d - p.pad >= 0 && cy + d - p.pad < p.Hin) my |= 1u << d;
+          if (cx + d - p.pad >= 0 && cx + d - p.pad < p.Win) mx |= 1u << d;
+        }
+        unsigned mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          if (((my >> (t / 3)) & 1u) && ((mx >> (t % 3)) & 1u)) mask |= 1u << t;
+        a_b[i] = ok ? (int)mask : 0;
+        a_px[i] = (b * p.Hin + cy) * p.Win + cx;
+      } else {
+        a_b[i] = ok ? b : -1; a_px[i] = (oy << 16) | ox;
+      }
     }
   }
   // weight rows: the launcher guarantees N % BN == 0, so every row exists.  One 32-bit byte offset per
@@ -540,31 +564,84 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
       acur[i] = ok ? base + (pix * cs + (size_t)cseg * BK) * sizeof(T) + sc * 16 : zero;
     }
   };
-  {
+  // tap-inner walk: wave-uniform position (slice, tap = dy * 3 + dx), byte offset of the tap relative
+  // to the centre pixel, and the step of the weight offset to the next K-tile
+  int ti_chunk = 0, ti_tap = 0, ti_dy = 0, ti_dx = 0, ti_cs2 = 0, ti_rowpitch = 0;
+  long ti_soff = 0;
+  unsigned w_step = 128;
+  const int ctot2 = (p.c0 + p.c1) * (int)sizeof(T);
+  auto set_source = [&](int chunk) {      // acur = centre pixel of every row in slice `chunk`
+    const int src = chunk >= tiles_c0 ? 1 : 0;
+    const char* base = src ? p.a1 : p.a0;
+    const int cs = src ? p.c1 : p.c0;
+    const int cseg = src ? chunk - tiles_c0 : chunk;
+    ti_cs2 = cs * (int)sizeof(T);
+    ti_rowpitch = p.Win * ti_cs2;
+    ti_soff = (long)(ti_dy - p.pad) * ti_rowpitch + (long)(ti_dx - p.pad) * ti_cs2;
+#pragma unroll
+    for (int i = 0; i < AP; ++i)
+      acur[i] = base + ((size_t)a_px[i] * cs + (size_t)cseg * BK) * sizeof(T) + sc * 16;
+  };
+  if constexpr (tapinner) {
+    ti_chunk = kt_begin / 9;
+    ti_tap = kt_begin - ti_chunk * 9;
+    ti_dy = ti_tap / 3;
+    ti_dx = ti_tap - ti_dy * 3;
+    set_source(ti_chunk);
+    wofs = (unsigned)(((size_t)(n0 + wp_first * 8 + lrow) * p.K) * sizeof(T)) + sc * 16 +
+           (unsigned)(ti_tap * ctot2 + ti_chunk * (BK * (int)sizeof(T)));
+  } else {
     const int tap = kt_begin / tiles_tap, rem = kt_begin - tap * tiles_tap;
     const int src = rem >= tiles_c0 ? 1 : 0;
     set_segment(tap, src, src ? rem - tiles_c0 : rem);
   }
   auto prefetch_a = [&](int stage) {
     char* abuf = smem + stage * S::STAGE_BYTES;
+    if constexpr (tapinner) {
+      const unsigned bit = 1u << ti_tap;
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      glds16(acur[i], abuf + (wid * AP + i) * 1024);
-      acur[i] += acur[i] != zero ? 128 : 0;
-    }
-    if (--pf_left == 0) {
-      int tap = pf_tap, src = pf_src;
-      if (src == 0 && tiles_c1 > 0) src = 1;
-      else { src = 0; ++tap; }
-      if (tap < p.taps) set_segment(tap, src, 0);
+      for (int i = 0; i < AP; ++i) {
+        const char* src = acur[i] + ti_soff;
+        glds16(((unsigned)a_b[i] & bit) ? src : zero, abuf + (wid * AP + i) * 1024);
+      }
+      if (ti_tap == 8) {
+        w_step = (unsigned)(BK * (int)sizeof(T) - 8 * ctot2);
+        ti_tap = 0; ti_dy = 0; ti_dx = 0;
+        ++ti_chunk;
+        if (ti_chunk == tiles_c0 && tiles_c1 > 0) {
+          set_source(ti_chunk);
+        } else {
+          ti_soff = -(long)p.pad * (ti_rowpitch + ti_cs2);
+#pragma unroll
+          for (int i = 0; i < AP; ++i) acur[i] += BK * sizeof(T);
+        }
+      } else {
+        w_step = (unsigned)ctot2;
+        ++ti_tap;
+        if (ti_dx == 2) { ti_dx = 0; ++ti_dy; ti_soff += ti_rowpitch - 2 * ti_cs2; }
+        else { ++ti_dx; ti_soff += ti_cs2; }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        glds16(acur[i], abuf + (wid * AP + i) * 1024);
+        acur[i] += acur[i] != zero ? 128 : 0;
+      }
+      if (--pf_left == 0) {
+        int tap = pf_tap, src = pf_src;
+        if (src == 0 && tiles_c1 > 0) src = 1;
+        else { src = 0; ++tap; }
+        if (tap < p.taps) set_segment(tap, src, 0);
+      }
     }
   };
-  auto prefetch_w = [&](int stage) {
+  auto prefetch_w = [&](int stage) {      // follows prefetch_a of the same tile (w_step)
     char* wbuf = smem + stage * S::STAGE_BYTES + S::A_BYTES + wp_first * 1024;
 #pragma unroll
     for (int i = 0; i < S::WP_LO; ++i) glds16(p.w + i * wpitch8 + wofs, wbuf + i * 1024);
     if (wp_extra) glds16(p.w + S::WP_LO * wpitch8 + wofs, wbuf + S::WP_LO * 1024);
-    wofs += 128;
+    if constexpr (tapinner) wofs += w_step;
+    else wofs += 128;
   };
   // wait until at most one tile's worth of this wave's DMA is still in flight (three-stage ring)
   auto wait_keep_one_tile = [&]() {
@@ -724,13 +801,21 @@ int set_lds_limits() {
   SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_kernel<T, ShapeSmall>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, ShapeSmall::LDS_BYTES));
   if constexpr (sizeof(T) == 2) {
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP320>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP320, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP320::LDS_BYTES));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP256>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP320, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP320::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP256, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP256::LDS_BYTES));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP256, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP256::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160::LDS_BYTES));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP160::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP160H::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160H::LDS_BYTES));
   }
   return SDMI_OK;
@@ -842,14 +927,29 @@ Plan make_plan(int M, int N, int K, int dtype, bool geglu) {
   return best;
 }
 
+// K order of the large-tile kernels.  Taps innermost pays when a workgroup is the only reader of its
+// activation rows (one tile along N): measured -10 % on the 320-channel 3x3 convolutions at 64x64.
+// With several tiles along N the neighbouring workgroups of the XCD already share those rows in L2 and
+// the tap-major walk, whose loader is a little cheaper, stays ahead (+4..11 % the other way).
+// SDMI_GEMM_TAP_INNER=0/1 overrides where legal (tests and experiments; read on every call).
+bool use_tap_inner(const GemmParams& p) {
+  if (p.taps != 9 || p.up) return false;
+  const char* e = getenv("SDMI_GEMM_TAP_INNER");
+  if (e) return atoi(e) != 0;
+  return p.tiles_n == 1;
+}
+
 // kernel for an explicit split count (callers size the slab with conv_gemm_pick_splits)
 int pick_kind(int M, int N, int K, int dtype, bool geglu) { return make_plan(M, N, K, dtype, geglu).kind; }
 
 template <typename T, typename S>
 void launch_pp(GemmParams& p, int splits, hipStream_t stream) {
   p.tiles_m = (p.M + S::BM - 1) / S::BM; p.tiles_n = p.N / S::BN;
-  hipLaunchKernelGGL((conv_gemm_pp_kernel<T, S>), dim3(p.tiles_m * p.tiles_n, splits), dim3(S::NTHREADS),
-                     S::LDS_BYTES, stream, p);
+  const dim3 grid(p.tiles_m * p.tiles_n, splits), block(S::NTHREADS);
+  if (use_tap_inner(p))
+    hipLaunchKernelGGL((conv_gemm_pp_kernel<T, S, true>), grid, block, S::LDS_BYTES, stream, p);
+  else
+    hipLaunchKernelGGL((conv_gemm_pp_kernel<T, S, false>), grid, block, S::LDS_BYTES, stream, p);
 }
 
 template <typename T>

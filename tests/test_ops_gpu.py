@@ -124,6 +124,25 @@ def test_conv2d_tiles_128x160(ops, dt, case, monkeypatch):
 
 
 @pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("order", ["0", "1"])
+@pytest.mark.parametrize("shape", ["2", "3", "4"])
+def test_large_tiles_both_k_orders(ops, dt, order, shape, monkeypatch):
+    """3x3 convolutions through the tap-major and the tap-inner K walk of every large-tile shape: concat
+    sources, stride 2, ragged M, split-K (splits start mid-slice), long K, the encoder's asymmetric padding."""
+    monkeypatch.setenv("SDMI_GEMM_SHAPE", shape)
+    monkeypatch.setenv("SDMI_GEMM_TAP_INNER", order)
+    for case in PP_CASES:
+        if case[7] == 9:
+            test_conv2d(ops, dt, case)
+    test_conv2d(ops, dt, ("pp_long_k_split", 1, 16, 16, 448, 192, 320, 9, 1, 0, 5))
+    x = q(rnd("order.x", (1, 64, 12, 20)), dt)
+    w = q(rnd("order.w", (320, 64, 3, 3), -0.05, 0.05), dt)
+    ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, None, stride=2, padding=0)
+    y = ops.conv2d(nhwc(x, dt), ops.pack_weight(w.cuda(), dt), None, taps=9, stride=2, pad_lo=0)
+    assert max_rel_err(nchw(y), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
 @pytest.mark.parametrize("shape", ["2", "3", "4"])
 def test_large_tiles_direct_store_path(ops, dt, shape, monkeypatch):
     """The store path for outputs that are not 16-byte addressable (straight from the accumulator layout)."""

@@ -50,6 +50,7 @@ struct FlashParams {
   const char* q; const char* k; const char* v; char* out;
   int ldq, ldk, ldv, ldo;      // in elements
   int B, heads, Nq, Nk;
+  int qblocks;                 // 128-query blocks per (batch, head)
   float c;                     // scale * log2(e)
   int causal;                  // keys beyond the query's own index are masked
 };
@@ -84,8 +85,19 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : (D <= 80 ? 2 : 1))) void attn_f
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int bh = blockIdx.y, b = bh / p.heads, hd = bh - b * p.heads;
-  const int qi = blockIdx.x * 128 + wid * 32 + r;
+  // XCD-aware order: consecutive workgroup ids go round the 8 XCDs, so the ids dealt to one XCD (id % 8)
+  // are given a contiguous range of work items, query block fastest: the query blocks of a (batch, head)
+  // then run on the same XCD and its K/V stays in that XCD's L2.
+  int qblk, bh;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, x = bid & 7;
+    const int id = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (bid >> 3);
+    bh = id / p.qblocks;
+    qblk = id - bh * p.qblocks;
+  }
+  const int b = bh / p.heads, hd = bh - b * p.heads;
+  const int qi = qblk * 128 + wid * 32 + r;
   const int qrow = min(qi, p.Nq - 1);
 
   // ---- Q fragments (B operand of K Q^T): dims 16s + 8h .. +7 of this lane's query ---------------
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : (D <= 80 ? 2 : 1))) void attn_f
       }
     }
 
-    if (p.causal && t * KV_TILE + KV_TILE - 1 > blockIdx.x * 128 + wid * 32) {
+    if (p.causal && t * KV_TILE + KV_TILE - 1 > qblk * 128 + wid * 32) {
       const int kbase_i = t * KV_TILE + 4 * h;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -343,7 +355,8 @@ int launch_flash(const AttentionArgs& a, hipStream_t stream) {
   p.c = a.scale * 1.4426950408889634f;
   p.causal = a.causal;
   const int lds = 2 * G::STAGE;
-  dim3 grid((a.Nq + 127) / 128, a.B * a.heads);
+  p.qblocks = (a.Nq + 127) / 128;
+  dim3 grid(p.qblocks * a.B * a.heads);
   hipLaunchKernelGGL((attn_flash_kernel<T, D>), grid, dim3(256), lds, stream, p);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;

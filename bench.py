@@ -10,6 +10,14 @@ tokenizer's output (--no-clip: context tensors instead), inputs resident in HBM.
 rank runs its own batch (weak scaling; samples are independent trajectories) and the decoded images
 are all-gathered over RCCL inside the timed region.  Rank 0 prints one JSON line.
 
+`--gpus N` with N > 1 outside a torchrun launch starts the N ranks itself: the parent process, before it
+touches the GPU, runs `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>` as a child,
+relays the child's JSON line and exits with its code.  Under torchrun, `--gpus` must equal WORLD_SIZE.
+
+`--total-images T` switches to the fixed-list mode (strong scaling): the T samples of the global list are
+dealt to the ranks in contiguous blocks, each rank walks its block in batches of `--batch`, and a "step" is
+the whole list including the all-gather; value = T / (max over ranks of the step time).
+
 Extra objects on that line:
   roofline      dominant kernel (implicit-GEMM conv/linear on MFMA): algorithmic FLOPs of its launches /
                 their HIP-event time, measured in this process on one extra eager pass of the same step
@@ -35,6 +43,12 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3}
 UNET_GFLOP_PER_SAMPLE = 803.3        # one sample-forward at latent 64x64 (algorithmic, 2*MACs)
 VAE_GFLOP_PER_IMAGE = 2514.5
+# Work the sampler's CFG-pair shortcut does not execute, per pair and UNet call at latent 64x64: the two halves
+# of x_in = cat([x] * 2) are identical up to the first cross-attention, so the first ResBlock (two 3x3 convs
+# 320 -> 320 on 4096 pixels), proj_in, the fused q/k/v projection, the 8-head d=40 self-attention over 4096
+# tokens, its output projection and the cross-attention query projection run for one of the two samples.
+_PX, _D = 4096, 320
+CFG_PAIR_SKIPPED_GFLOP = 2 * (2 * 9 * _PX * _D * _D + 6 * _PX * _D * _D + 2 * _PX * _PX * _D) / 1e9
 
 
 def parse():
@@ -42,7 +56,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (per batch with --total-images)")
+    ap.add_argument("--total-images", type=int, default=0, help="fixed list of this many samples sharded over "
+                    "the ranks in batches of --batch (strong scaling); 0 = one batch per rank (weak scaling)")
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
@@ -148,9 +164,39 @@ def log(rank, msg):
     print(f"[bench rank {rank} +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def spawn_ranks(args):
+    """Parent of a multi-rank run that was not started by torchrun: start the ranks as a child process (this
+    process has made no GPU call and makes none), pass the rank-0 JSON line through and return the child's code."""
+    import socket
+    import subprocess
+    share = os.environ.get("SDMI_BENCH_SHARE_DEVICE") == "1"
+    have = torch.cuda.device_count()              # counting devices does not initialise the GPU
+    if have < args.gpus and not share:
+        print(f"bench.py: --gpus {args.gpus} but only {have} device(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        # stdout carries exactly the JSON line; anything else a rank or the launcher printed goes to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE {world}", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
@@ -183,19 +229,28 @@ def main():
         unet.set_graph_mode(False)
     sampler = sdmi.DDIMSampler(model)
     B, h = args.batch, args.size // 8
-    first = rank * B                                   # this rank's block of the global sample list
-    if args.no_clip:
-        uc, c = pipeline.synthetic_conditioning(B, dev, first_sample=first)
-    else:
-        uc, c = pipeline.synthetic_prompt_tokens(B, dev, first_sample=first)
-    x_T = pipeline.initial_latents(B, h, h, dev, first_sample=first)
+    total = args.total_images if args.total_images > 0 else world * B
+    lo, hi = pipeline.shard(total, rank, world)        # this rank's block of the global sample list
 
-    def local_step():
+    # inputs of every batch of the block, derived from the global sample index and resident in HBM
+    def batch_inputs(first, n):
+        if args.no_clip:
+            uc, c = pipeline.synthetic_conditioning(n, dev, first_sample=first)
+        else:
+            uc, c = pipeline.synthetic_prompt_tokens(n, dev, first_sample=first)
+        return pipeline.initial_latents(n, h, h, dev, first_sample=first), uc, c
+    inputs = {first: batch_inputs(first, n) for first, n in pipeline.sample_batches(lo, hi, B)}
+
+    def run_batch(first, n):
+        x_T, uc, c = inputs[first]
         img, _ = pipeline.txt2img(model, x_T, uc, c, steps=args.ddim_steps, scale=args.scale, sampler=sampler)
         return img
 
+    def local_step():
+        return [run_batch(first, n) for first, n in pipeline.sample_batches(lo, hi, B)]
+
     def step():
-        return pipeline.gather_images(local_step())
+        return pipeline.gather_sharded(local_step(), total, rank, world)
 
     def fence():
         torch.cuda.synchronize()
@@ -217,21 +272,23 @@ def main():
         tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    assert out.shape[0] == world * B and bool(torch.isfinite(out).all())
-    images = world * B * args.steps
+    assert out.shape[0] == total and bool(torch.isfinite(out).all())
+    images = total * args.steps
     value = images / elapsed
 
     result = {
         "metric": "images/sec (node) 512x512 50-step DDIM CFG; UNet it/s at batch 2",
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "strong" if args.total_images > 0 else "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"txt2img {args.size}x{args.size}, {args.ddim_steps} DDIM steps, CFG {args.scale}, "
-                               f"batch {B}/GPU (UNet batch {2 * B}), "
+                               + (f"fixed list of {total} samples in batches of {B} (UNet batch {2 * B}), "
+                                  if args.total_images > 0 else f"batch {B}/GPU (UNet batch {2 * B}), ")
                                + ("context tensors in place of CLIP" if args.no_clip else
                                   "CLIP text transformer on synthetic token ids") +
                                " + UNet loop + fused CFG/DDIM update + VAE decode + clamp; SD-v1-shaped random weights",
-                   "global_batch": world * B, "latent": [4, h, h], "parallelism": f"replicas x{world} (sample shard)",
+                   "global_batch": total, "latent": [4, h, h], "parallelism": f"replicas x{world} (sample shard)",
                    "graph_replay": not args.no_graph},
     }
 
@@ -255,9 +312,11 @@ def main():
         result["unet_batch2_ms"] = 1e3 * dt2
         result["unet_batch2_tflops"] = 2 * UNET_GFLOP_PER_SAMPLE / dt2 / 1e3
         # whole-step algorithmic rate
-        step_tflop = (B * (2 * UNET_GFLOP_PER_SAMPLE * args.ddim_steps + VAE_GFLOP_PER_IMAGE)) / 1e3
         if args.size == 512:
-            result["step_tflops"] = step_tflop / (elapsed / args.steps)
+            # whole-step rate on the work actually executed (the CFG-pair shortcut's skipped layers are not counted)
+            per_image = (2 * UNET_GFLOP_PER_SAMPLE - CFG_PAIR_SKIPPED_GFLOP) * args.ddim_steps + VAE_GFLOP_PER_IMAGE
+            result["step_tflops"] = total * per_image / 1e3 / (elapsed / args.steps)
+            result["step_tflop_executed"] = total * per_image / 1e3
 
     if rank == 0 and not args.no_roofline:
         log(rank, "roofline pass")
@@ -265,7 +324,7 @@ def main():
         unet.set_graph_mode(False)
         lib.sdmi_prof_reset()
         lib.sdmi_prof_enable(1)
-        local_step()              # rank 0 alone: no collective in this pass
+        run_batch(*pipeline.sample_batches(lo, hi, B)[0])      # rank 0 alone, one batch: no collective in this pass
         torch.cuda.synchronize()
         lib.sdmi_prof_enable(0)
         gemm = prof_read(lib, "conv_gemm")

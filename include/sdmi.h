@@ -84,6 +84,15 @@ int sdmi_unet_set_context(sdmi_unet* u, const void* ctx, int batch, int ntok, vo
  * The context set by sdmi_unet_set_context must have the same batch. */
 int sdmi_unet_forward(sdmi_unet* u, const void* x, const void* const* concat, const int* concat_channels,
                       int n_concat, const int64_t* t, void* out, int batch, int h, int w, void* stream);
+/* One block of the denoiser on its own, through the code path sdmi_unet_forward uses for it: replaces
+ * ResBlock.forward(x, emb) :3197-3234 (kind 0) and SpatialTransformer.forward(x, context) :2885-2896 (kind 1,
+ * context = the one given to sdmi_unet_set_context).  index counts the blocks of that kind in construction
+ * order (ResBlocks: input_blocks.1.0, input_blocks.2.0, ...; transformers: input_blocks.1.1, ...).
+ * x, out: NHWC [batch][h][w][channels] in the handle's compute dtype; x_skip: optional second input that is
+ * channel-concatenated behind x (the skip tensor of an output block), c_skip its channels; emb: fp32
+ * [batch][4 * model_channels], the output of time_embed (the block applies its own SiLU + Linear). */
+int sdmi_unet_run_block(sdmi_unet* u, int kind, int index, const void* x, const void* x_skip, int c_skip,
+                        const float* emb, void* out, int batch, int h, int w, void* stream);
 /* 1: the caller promises that every sample of the following forwards carries the same timestep (the
  * DDIM loop's torch.full((b,), step), :5308): the time-embedding MLP then runs on t[0] only.  Default 0. */
 int sdmi_unet_set_uniform_timesteps(sdmi_unet* u, int enable);
@@ -116,6 +125,14 @@ int sdmi_ddim_step(const void* x, const void* eps, int cfg, float scale, float a
 int sdmi_ddpm_step(const void* x, const void* eps, float sqrt_recip_acp, float sqrt_recipm1_acp,
                    int clip_denoised, float mean_coef1, float mean_coef2, float noise_coef, const void* noise,
                    float temperature, void* x_prev, void* pred_x0, int64_t n, void* stream);
+/* Known-region blend of the DDIM loop, replaces DDIMSampler.ddim_sampling :5316-5319 with DDPM.q_sample
+ * :3892-3895 inlined:  out = (sqrt_acp * x0 + sqrt_one_minus_acp * noise) * mask + (1 - mask) * img.
+ * The two scalars are sqrt_alphas_cumprod[t] / sqrt_one_minus_alphas_cumprod[t] of the step's timestep (one
+ * t for the whole batch, :5314).  x0, noise, img, out: fp32 [batch][channels][hw]; mask: fp32
+ * [batch][mask_channels][hw], mask_channels 1 (broadcast over channels) or `channels`.  out may alias img. */
+int sdmi_q_sample_blend(const void* x0, const void* noise, const void* mask, const void* img, float sqrt_acp,
+                        float sqrt_one_minus_acp, void* out, int batch, int channels, int hw, int mask_channels,
+                        void* stream);
 /* out = ca * a + cb * b */
 int sdmi_axpby(const void* a, const void* b, float ca, float cb, void* out, int64_t n, void* stream);
 

@@ -335,6 +335,44 @@ def g10(sdm, model):
 
 
 @torch.no_grad()
+def g13(sdm, model):
+    """DDIM sampling with a known region: DDIMSampler.sample(mask=, x0=) (:5316-5319 with q_sample :3892-3895),
+    S=4 at a 16x16 latent, CFG 7.5.  The noise q_sample draws (torch.randn_like) and the blended latent each step
+    hands to p_sample_ddim are recorded on the way through; nothing of the sampler is replaced."""
+    sampler = sdm.DDIMSampler(model)
+    h = 16
+    x_T = synth.normal(42, "g13.x_T", (1, 4, h, h))
+    x0 = synth.normal(43, "g13.x0", (1, 4, h, h)) * 0.8
+    m = synth.uniform01(44, "g13.mask", h * h).reshape(1, 1, h, h)
+    # hard keep / repaint regions and a soft band in between
+    mask = torch.where(m < 0.4, torch.zeros_like(m), torch.where(m > 0.6, torch.ones_like(m), m))
+    uc, c = cfg_context(1)
+    q_noise, blended = [], []
+    orig_randn_like, orig_step = torch.randn_like, sampler.p_sample_ddim
+
+    def rec_randn_like(t, **kw):
+        n = orig_randn_like(t, **kw)
+        q_noise.append(n.clone())
+        return n
+
+    def rec_step(x, *a, **kw):
+        blended.append(x.clone())
+        return orig_step(x, *a, **kw)
+
+    torch.randn_like, sampler.p_sample_ddim = rec_randn_like, rec_step
+    try:
+        torch.manual_seed(13)
+        z, _ = sampler.sample(S=4, batch_size=1, shape=[4, h, h], conditioning=torch.cat([uc, c]), mask=mask, x0=x0,
+                              unconditional_guidance_scale=7.5, unconditional_conditioning=True, eta=0., x_T=x_T,
+                              verbose=False)
+    finally:
+        torch.randn_like, sampler.p_sample_ddim = orig_randn_like, orig_step
+    assert len(q_noise) == 4 and len(blended) == 4
+    save("g13_mask_blend", x_T=x_T, x0=x0, mask=mask, uc=uc.half(), c=c.half(), q_noise=torch.stack(q_noise),
+         blended=torch.stack(blended), z=z)
+
+
+@torch.no_grad()
 def g12():
     """Text conditioner: the model FrozenCLIPEmbedder.forward runs (:2557-2574), i.e. the installed
     transformers' CLIPTextModel in the ViT-L/14 text configuration, with synthesised weights and synthetic
@@ -366,11 +404,11 @@ def g12():
 
 
 def main(argv):
-    names = argv or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g9b", "g7", "g10", "g11", "g12"]
+    names = argv or ["g1", "g2", "g3", "g4", "g5", "g6", "g8", "g9", "g9b", "g7", "g10", "g11", "g12", "g13"]
     torch.manual_seed(0)
     sdm = import_reference()
     model = None
-    need_model = {"g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"} & set(names)
+    need_model = {"g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g13"} & set(names)
     for n in names:
         t0 = time.time()
         if n == "g12":
@@ -386,7 +424,8 @@ def main(argv):
         else:
             if model is None and need_model:
                 model = ref_latent_diffusion(sdm)
-            {"g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}[n](sdm, model)
+            {"g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11,
+             "g13": g13}[n](sdm, model)
         print(f"[{n}] done in {time.time() - t0:.1f}s", flush=True)
 
 

@@ -85,12 +85,26 @@ def stochastic_encode(x0, t_index, tab, noise):
     return sa.gather(-1, t).reshape(shp) * x0 + s1.gather(-1, t).reshape(shp) * noise
 
 
+def q_sample(x_start, t, tab, noise):
+    """DDPM.q_sample :3892-3895 with the 1000-step tables; ``t`` is a (b,) long tensor of timesteps."""
+    shp = (x_start.shape[0],) + (1,) * (x_start.dim() - 1)
+    return (tab["sqrt_alphas_cumprod"][t].reshape(shp) * x_start +
+            tab["sqrt_one_minus_alphas_cumprod"][t].reshape(shp) * noise)
+
+
+def known_region_blend(x0, t, tab, noise, mask, img):
+    """ddim_sampling :5316-5319: the known latent noised to the step's timestep replaces the masked region."""
+    return q_sample(x0, t, tab, noise) * mask + (1. - mask) * img
+
+
 @torch.no_grad()
-def ddim_loop(eps_model, x_T, S, eta, scale, tables_ddpm, noises=None, t_start=None):
+def ddim_loop(eps_model, x_T, S, eta, scale, tables_ddpm, noises=None, t_start=None, mask=None, x0=None,
+              q_noises=None):
     """ddim_sampling :5276-5335 / decode :5394-5412 with the CFG contract: ``eps_model(x_in, t_in)``
     receives the doubled batch [x; x] and returns eps for [uncond; cond] (:5344-5346).
 
-    t_start=None runs all S steps (sample); otherwise the first t_start timesteps (decode)."""
+    t_start=None runs all S steps (sample); otherwise the first t_start timesteps (decode).  ``mask`` / ``x0`` /
+    ``q_noises`` (one noise tensor per step) add the known-region blend of :5316-5319."""
     tab = ddim_tables(tables_ddpm["alphas_cumprod"], S, eta)
     ts = tab["timesteps"] if t_start is None else tab["timesteps"][:t_start]
     total = ts.shape[0]
@@ -99,6 +113,8 @@ def ddim_loop(eps_model, x_T, S, eta, scale, tables_ddpm, noises=None, t_start=N
     for i, step in enumerate(np.flip(ts)):
         index = total - i - 1
         t = torch.full((b,), int(step), dtype=torch.long)
+        if mask is not None:
+            img = known_region_blend(x0, t, tables_ddpm, q_noises[i], mask, img)
         if scale != 1.:
             e_u, e_c = eps_model(torch.cat([img] * 2), torch.cat([t] * 2)).chunk(2)
             e_t = cfg_combine(e_u, e_c, scale)

@@ -49,6 +49,8 @@ SIGNATURES = {
     "sdmi_unet_set_context": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "sdmi_unet_forward": (c_int, [c_void_p, c_void_p, P(c_void_p), P(c_int), c_int, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_void_p]),
+    "sdmi_unet_run_block": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                    c_int, c_void_p]),
     "sdmi_unet_device_bytes": (c_int64, [c_void_p]),
     "sdmi_unet_set_graph_mode": (c_int, [c_void_p, c_int]),
     "sdmi_unet_set_uniform_timesteps": (c_int, [c_void_p, c_int]),
@@ -59,6 +61,8 @@ SIGNATURES = {
     "sdmi_ddpm_step": (c_int, [c_void_p, c_void_p, c_float, c_float, c_int, c_float, c_float, c_float, c_void_p,
                                c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     "sdmi_axpby": (c_int, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
+    "sdmi_q_sample_blend": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_int, c_int,
+                                    c_int, c_int, c_void_p]),
     "sdmi_vae_decoder_create": (c_int, [P(VaeCfg), P(c_void_p)]),
     "sdmi_vae_decoder_num_weights": (c_int, [c_void_p]),
     "sdmi_vae_decoder_weight_info": (c_int, [c_void_p, c_int, P(c_char_p), P(c_int64), P(c_int)]),

@@ -101,12 +101,14 @@ class AutoencoderKL:
     """Drop-in for stable_diffusion.AutoencoderKL on the decode path."""
 
     def __init__(self, ddconfig, lossconfig=None, embed_dim=4, ckpt_path=None, ignore_keys=(), image_key="image",
-                 colorize_nlabels=None, monitor=None, compute_dtype="fp16", device=None):
+                 colorize_nlabels=None, monitor=None, compute_dtype=None, device=None):
         assert ddconfig["double_z"]
         if ckpt_path is not None:
             raise NotImplementedError("pass tensors through load_state_dict (no checkpoint files offline)")
         self.ddconfig = dict(ddconfig)
         self.embed_dim = embed_dim
+        # the reference's autoencoder computes in fp32; the 16-bit fast paths are opt-in
+        compute_dtype = compute_dtype or "fp32"
         self.compute_dtype = compute_dtype
         self.device = torch.device(device if device is not None else "cuda")
         self._h = _create_handle(self.ddconfig, embed_dim, compute_dtype)

@@ -51,12 +51,13 @@ class FrozenCLIPEmbedder:
     entries of the ViT-L/14 text configuration (tests use small ones)."""
 
     def __init__(self, version="openai/clip-vit-large-patch14", device="cuda", max_length=77, tokenizer=None,
-                 config=None, compute_dtype="fp16"):
+                 config=None, compute_dtype=None):
         self.version = version
         self.device = torch.device(device)
         self.max_length = max_length
         self.tokenizer = tokenizer
         self.config = dict(CLIP_VIT_L14_TEXT, **(config or {}))
+        compute_dtype = compute_dtype or "fp32"      # the reference's text encoder computes in fp32; 16 bit is opt-in
         self.compute_dtype = compute_dtype
         c = self.config
         cfg = _lib.ClipCfg()

@@ -140,6 +140,13 @@ int sdmi_axpby(const void* a, const void* b, float ca, float cb, void* out, int6
   return axpby((const float*)a, (const float*)b, ca, cb, (float*)out, n, (hipStream_t)stream);
 }
 
+int sdmi_q_sample_blend(const void* x0, const void* noise, const void* mask, const void* img, float sqrt_acp,
+                        float sqrt_one_minus_acp, void* out, int batch, int channels, int hw, int mask_channels,
+                        void* stream) {
+  return q_sample_blend((const float*)x0, (const float*)noise, (const float*)mask, (const float*)img, sqrt_acp,
+                        sqrt_one_minus_acp, (float*)out, batch, channels, hw, mask_channels, (hipStream_t)stream);
+}
+
 int sdmi_to_image_u8(const void* x, void* out, int batch, int channels, int hw, void* stream) {
   return to_image_u8((const float*)x, (unsigned char*)out, batch, channels, hw, (hipStream_t)stream);
 }

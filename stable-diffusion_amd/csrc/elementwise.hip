@@ -270,6 +270,22 @@ __global__ void axpby_kernel(const float* a, const float* b, float ca, float cb,
     out[i] = ca * a[i] + cb * b[i];
 }
 
+// known-region blend of the DDIM loop: the known latent x0 is noised to the step's timestep (q_sample) and
+// written over the region mask marks; mask has 1 or `C` channels (broadcast over channels like the torch op)
+__global__ void q_sample_blend_kernel(const float* x0, const float* noise, const float* mask, const float* img,
+                                      float ca, float cb, float* out, int B, int C, int HW, int MC) {
+  // every product and sum is rounded separately, as the reference's elementwise torch ops are
+#pragma clang fp contract(off)
+  const size_t total = (size_t)B * C * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / ((size_t)C * HW), r = i - b * (size_t)C * HW;
+    const size_t c = r / HW, px = r - c * HW;
+    const float m = mask[(b * MC + (MC == 1 ? 0 : c)) * HW + px];
+    const float q = ca * x0[i] + cb * noise[i];
+    out[i] = q * m + (1.0f - m) * img[i];
+  }
+}
+
 __global__ void to_image_kernel(const float* x, float* out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = fminf(fmaxf((x[i] + 1.0f) / 2.0f, 0.f), 1.f);
@@ -522,6 +538,17 @@ int ddpm_step(const float* x, const float* eps, float c_recip, float c_recipm1, 
   SDMI_REQUIRE(x && eps && x_prev && n > 0, "ddpm_step: bad arguments");
   hipLaunchKernelGGL(ddpm_step_kernel, dim3(grid_for((size_t)n, 256, 2048)), dim3(256), 0, s, x, eps, c_recip,
                      c_recipm1, clip, coef1, coef2, noise_coef, noise, temperature, x_prev, pred_x0, n);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int q_sample_blend(const float* x0, const float* noise, const float* mask, const float* img, float ca, float cb,
+                   float* out, int B, int C, int HW, int mask_channels, hipStream_t s) {
+  SDMI_REQUIRE(x0 && noise && mask && img && out && B > 0 && C > 0 && HW > 0, "q_sample_blend: bad arguments");
+  SDMI_REQUIRE(mask_channels == 1 || mask_channels == C, "q_sample_blend: mask has %d channels, expected 1 or %d",
+               mask_channels, C);
+  hipLaunchKernelGGL(q_sample_blend_kernel, dim3(grid_for((size_t)B * C * HW, 256, 2048)), dim3(256), 0, s, x0, noise,
+                     mask, img, ca, cb, out, B, C, HW, mask_channels);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

@@ -135,6 +135,9 @@ int ddpm_step(const float* x, const float* eps, float c_recip, float c_recipm1, 
               hipStream_t s);
 // out = ca * a + cb * b   (stochastic_encode / q_sample with per-call scalars; fp32)
 int axpby(const float* a, const float* b, float ca, float cb, float* out, int64_t n, hipStream_t s);
+// known-region blend of the DDIM loop (fp32): out = (ca x0 + cb noise) * mask + (1 - mask) * img; mask has 1 or C channels
+int q_sample_blend(const float* x0, const float* noise, const float* mask, const float* img, float ca, float cb,
+                   float* out, int B, int C, int HW, int mask_channels, hipStream_t s);
 // row softmax over fp32 scores -> dtype probabilities (VAE mid-block attention, two-pass path)
 int softmax_rows(const float* s, void* p, int rows, int cols, float scale, int dtype, hipStream_t st);
 // out[i] = clamp((x[i]+1)/2, 0, 1)

@@ -109,6 +109,7 @@ struct sdmi_unet {
     bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
   };
   GraphKey gkey; bool ghave = false;
+  GraphKey gseen; bool gseen_have = false;   // key of the last eager forward: a graph is recorded on its second sighting
   hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
   hipStream_t cap_stream = nullptr;      // capture happens here; replay goes to the caller's stream
 
@@ -614,6 +615,48 @@ struct sdmi_unet {
     return SDMI_OK;
   }
 
+  // One ResBlock or SpatialTransformer of the layer list on its own, through the same code as forward()
+  int run_block(int kind, int index, const void* x, const void* x_skip, int c_skip, const float* emb, void* out,
+                int B, int H, int W, hipStream_t s) {
+    if (!finalized) { sdmi_set_error("run_block before finalize"); return SDMI_ESTATE; }
+    SDMI_REQUIRE(x && out && B > 0 && H > 0 && W > 0, "run_block: bad arguments");
+    SDMI_REQUIRE(kind == 0 || kind == 1, "run_block: kind must be 0 (ResBlock) or 1 (SpatialTransformer)");
+    SDMI_REQUIRE(index >= 0 && index < (int)(kind == 0 ? res.size() : sts.size()), "run_block: no block %d", index);
+    SDMI_REQUIRE(kind == 0 ? emb != nullptr : ctx_batch == B,
+                 kind == 0 ? "run_block: a ResBlock needs emb" : "run_block: context was set for another batch");
+    SDMI_REQUIRE(kind == 0 || !x_skip, "run_block: only a ResBlock takes a second input");
+    Fwd f;
+    memset(&f, 0, sizeof(f));
+    f.B = B; f.H = H; f.W = W; f.s = s;
+    auto body = [&]() -> int {
+      Tensor y;
+      if (kind == 0) {
+        const ResW& r = res[index];
+        float* emb_all = (float*)ws.get("emb_all", (size_t)B * emb_total * 4);
+        emb_rows = B;
+        if (!ws.dry) SDMI_TRY(small_linear(emb, emb_w_all, emb_b_all, emb_all, B, temb, emb_total, 1, 0, s));
+        Tensor x0{const_cast<void*>(x), H, W, r.cin - (x_skip ? c_skip : 0)};
+        Tensor x1{const_cast<void*>(x_skip), H, W, c_skip};
+        SDMI_TRY(run_res(r, x0, x_skip ? &x1 : nullptr, &y, "blk_out", emb_all, f));
+      } else {
+        Tensor x0{const_cast<void*>(x), H, W, sts[index].ch};
+        SDMI_TRY(run_st(sts[index], x0, &y, "blk_out", f));
+      }
+      if (!ws.dry)
+        SDMI_CHECK_HIP(hipMemcpyAsync(out, y.p, act_bytes(B, H, W, y.C), hipMemcpyDeviceToDevice, s));
+      return SDMI_OK;
+    };
+    ws.dry = true; ws.need.clear();
+    SDMI_TRY(body());
+    ws.dry = false;
+    if (!ws.fits()) {
+      drop_graph();
+      SDMI_CHECK_HIP(hipStreamSynchronize(s));
+      SDMI_TRY(ws.commit());
+    }
+    return body();
+  }
+
   int forward(const Fwd& f) {
     if (!finalized) { sdmi_set_error("forward before finalize"); return SDMI_ESTATE; }
     SDMI_REQUIRE(f.x && f.t && f.out && f.B > 0 && f.H > 0 && f.W > 0, "forward: bad arguments");
@@ -637,6 +680,13 @@ struct sdmi_unet {
     k.t = f.t; k.out = f.out; k.n_concat = f.n_concat; k.cc0 = f.cc[0]; k.cc1 = f.cc[1];
     k.B = f.B; k.H = f.H; k.W = f.W; k.uniform_t = uniform_t; k.cfg_dup = cfg_dup; k.stream = nullptr;
     if (!(ghave && k == gkey)) {
+      // Recording and instantiating a graph costs more than an eager forward, so a key earns its graph by
+      // coming back: a caller that hands over fresh buffers on every call (new x / t / out addresses) runs
+      // eagerly throughout, a sampling loop with persistent buffers replays from its third step on.
+      if (!(gseen_have && k == gseen)) {
+        gseen = k; gseen_have = true;
+        return run(f);
+      }
       drop_graph();
       // the caller's stream may be the legacy default stream, which cannot be captured: record the
       // launch sequence on a private stream (nothing executes there) and replay it on f.s
@@ -720,6 +770,12 @@ int sdmi_unet_forward(sdmi_unet* u, const void* x, const void* const* concat, co
   for (int i = 0; i < n_concat; ++i) { f.concat[i] = (const float*)concat[i]; f.cc[i] = concat_channels[i]; }
   f.t = t; f.out = (float*)out; f.B = batch; f.H = h; f.W = w; f.s = (hipStream_t)stream;
   return u->forward(f);
+}
+
+int sdmi_unet_run_block(sdmi_unet* u, int kind, int index, const void* x, const void* x_skip, int c_skip,
+                        const float* emb, void* out, int batch, int h, int w, void* stream) {
+  SDMI_REQUIRE(u, "run_block: null handle");
+  return u->run_block(kind, index, x, x_skip, c_skip, emb, out, batch, h, w, (hipStream_t)stream);
 }
 
 int64_t sdmi_unet_device_bytes(const sdmi_unet* u) { return u ? (int64_t)u->mem.bytes : 0; }

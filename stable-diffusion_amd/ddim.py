@@ -57,31 +57,36 @@ class DDIMSampler(object):
     def register_buffer(self, name, attr):
         setattr(self, name, attr)
 
+    # derived 1000-step tables the sampler exposes: name -> function of the fp32 alphas_cumprod (as float64-free
+    # numpy-on-fp32 arithmetic, the way the reference derives them at :5197-5203)
+    _DERIVED = (("sqrt_alphas_cumprod", lambda ac: np.sqrt(ac)),
+                ("sqrt_one_minus_alphas_cumprod", lambda ac: np.sqrt(1. - ac)),
+                ("log_one_minus_alphas_cumprod", lambda ac: np.log(1. - ac)),
+                ("sqrt_recip_alphas_cumprod", lambda ac: np.sqrt(1. / ac)),
+                ("sqrt_recipm1_alphas_cumprod", lambda ac: np.sqrt(1. / ac - 1)))
+
     def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
-        self.ddim_timesteps = make_ddim_timesteps(ddim_discr_method=ddim_discretize,
-                                                  num_ddim_timesteps=ddim_num_steps,
-                                                  num_ddpm_timesteps=self.ddpm_num_timesteps, verbose=verbose)
-        alphas_cumprod = self.model.alphas_cumprod.cpu()
-        assert alphas_cumprod.shape[0] == self.ddpm_num_timesteps, 'alphas have to be defined for each timestep'
-        f32 = lambda x: x.clone().detach().to(torch.float32).cpu()
-        self.register_buffer('betas', f32(self.model.betas))
-        self.register_buffer('alphas_cumprod', f32(alphas_cumprod))
-        self.register_buffer('alphas_cumprod_prev', f32(self.model.alphas_cumprod_prev))
-        self.register_buffer('sqrt_alphas_cumprod', f32(np.sqrt(alphas_cumprod)))
-        self.register_buffer('sqrt_one_minus_alphas_cumprod', f32(np.sqrt(1. - alphas_cumprod)))
-        self.register_buffer('log_one_minus_alphas_cumprod', f32(np.log(1. - alphas_cumprod)))
-        self.register_buffer('sqrt_recip_alphas_cumprod', f32(np.sqrt(1. / alphas_cumprod)))
-        self.register_buffer('sqrt_recipm1_alphas_cumprod', f32(np.sqrt(1. / alphas_cumprod - 1)))
-        ddim_sigmas, ddim_alphas, ddim_alphas_prev = make_ddim_sampling_parameters(
-            alphacums=alphas_cumprod, ddim_timesteps=self.ddim_timesteps, eta=ddim_eta, verbose=verbose)
-        self.register_buffer('ddim_sigmas', ddim_sigmas)
-        self.register_buffer('ddim_alphas', ddim_alphas)
-        self.register_buffer('ddim_alphas_prev', ddim_alphas_prev)
-        self.register_buffer('ddim_sqrt_one_minus_alphas', np.sqrt(1. - ddim_alphas))
-        sigmas_for_original_sampling_steps = ddim_eta * torch.sqrt(
-            (1 - self.alphas_cumprod_prev) / (1 - self.alphas_cumprod) * (
-                1 - self.alphas_cumprod / self.alphas_cumprod_prev))
-        self.register_buffer('ddim_sigmas_for_original_num_steps', sigmas_for_original_sampling_steps)
+        """stable_diffusion.py:5180-5216.  All tables are small host tensors (the per-step scalars travel to the
+        fused update kernel as arguments); dtypes follow the reference: fp32 copies of the model's buffers, an
+        fp32 ``ddim_alphas``, float64 ``ddim_alphas_prev`` / ``ddim_sigmas``."""
+        model = self.model
+        acp = model.alphas_cumprod.cpu()
+        assert acp.shape[0] == self.ddpm_num_timesteps, 'alphas have to be defined for each timestep'
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps,
+                                                  verbose=verbose)
+        tables = {name: getattr(model, name) for name in ("betas", "alphas_cumprod", "alphas_cumprod_prev")}
+        tables.update((name, fn(acp.numpy())) for name, fn in self._DERIVED)
+        for name, value in tables.items():
+            self.register_buffer(name, torch.as_tensor(value).detach().to(torch.float32).cpu().clone())
+        sig, a, a_prev = make_ddim_sampling_parameters(alphacums=acp, ddim_timesteps=self.ddim_timesteps,
+                                                       eta=ddim_eta, verbose=verbose)
+        for name, value in (("ddim_sigmas", sig), ("ddim_alphas", a), ("ddim_alphas_prev", a_prev),
+                            ("ddim_sqrt_one_minus_alphas", torch.from_numpy(np.sqrt(1. - a.numpy())))):
+            self.register_buffer(name, value)
+        # sigma table for sampling on the original 1000 steps (use_original_steps=True), all fp32
+        a_t, a_tm1 = self.alphas_cumprod, self.alphas_cumprod_prev
+        self.register_buffer('ddim_sigmas_for_original_num_steps',
+                             ddim_eta * torch.sqrt((1 - a_tm1) / (1 - a_t) * (1 - a_t / a_tm1)))
 
     @torch.no_grad()
     def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None,
@@ -100,14 +105,14 @@ class DDIMSampler(object):
                                   log_every_t=log_every_t,
                                   unconditional_guidance_scale=unconditional_guidance_scale,
                                   unconditional_conditioning=unconditional_conditioning, verbose=verbose,
-                                  noise_fn=kwargs.get("noise_fn"))
+                                  noise_fn=kwargs.get("noise_fn"), q_noise_fn=kwargs.get("q_noise_fn"))
 
     @torch.no_grad()
     def ddim_sampling(self, conditioning, shape, x_T=None, ddim_use_original_steps=False, callback=None,
                       timesteps=None, quantize_denoised=False, mask=None, x0=None, img_callback=None,
                       log_every_t=100, temperature=1., noise_dropout=0., score_corrector=None,
                       corrector_kwargs=None, unconditional_guidance_scale=1., unconditional_conditioning=None,
-                      verbose=True, noise_fn=None):
+                      verbose=True, noise_fn=None, q_noise_fn=None):
         device = self.model.device
         b = shape[0]
         img = torch.randn(shape, device=device) if x_T is None else x_T.to(device, torch.float32)
@@ -128,11 +133,17 @@ class DDIMSampler(object):
         for i, step in enumerate(iterator):
             index = total_steps - i - 1
             if mask is not None:
+                # img = q_sample(x0, ts) * mask + (1 - mask) * img  (:5316-5319) as one kernel; the noise of
+                # q_sample (:3893) is drawn on the device unless the caller injects it
                 assert x0 is not None
-                ts = torch.full((b,), int(step), dtype=torch.long)
-                img_orig = self.model.q_sample(x0, ts)
-                m = mask.to(device, torch.float32)
-                st.set_x(img_orig * m + (1. - m) * st.x())
+                if i == 0:
+                    x0_d = x0.to(device, torch.float32).contiguous()
+                    m_d = mask.to(device, torch.float32).expand(b, -1, -1, -1).contiguous()
+                nz = q_noise_fn(x0_d.shape) if q_noise_fn is not None else torch.randn_like(x0_d)
+                nz = nz.to(device, torch.float32).contiguous()
+                st.set_x(ops.q_sample_blend(x0_d, nz, m_d, st.x().contiguous(),
+                                            self.model.sqrt_alphas_cumprod[int(step)],
+                                            self.model.sqrt_one_minus_alphas_cumprod[int(step)]))
             pred_x0 = st.step(cond, int(step), index, use_original_steps=ddim_use_original_steps,
                               quantize_denoised=quantize_denoised, temperature=temperature,
                               noise_dropout=noise_dropout, score_corrector=score_corrector,
@@ -232,7 +243,13 @@ class DDIMSampler(object):
         """One step with the reference's signature; returns (x_prev, pred_x0)."""
         doubled = bool(unconditional_conditioning) and unconditional_guidance_scale != 1.
         st = self._StepState(self, x, doubled)
+        t = torch.as_tensor(t).reshape(-1)
         t_value = int(t[0])
+        # the fused step feeds one timestep to the whole batch (what the sampling loops pass, :5314); per-sample
+        # timesteps would silently all become t[0]
+        if not bool((t == t_value).all()):
+            raise NotImplementedError("p_sample_ddim: per-sample timesteps are not on the MI355X sampling path "
+                                      "(the DDIM loops use one timestep per step); got " + str(t.tolist()))
         pred = st.step(c, t_value, index, use_original_steps=use_original_steps,
                        quantize_denoised=quantize_denoised, temperature=temperature, noise_dropout=noise_dropout,
                        score_corrector=score_corrector, unconditional_guidance_scale=unconditional_guidance_scale,
@@ -251,11 +268,7 @@ class DDIMSampler(object):
         if noise is None:
             noise = torch.randn_like(x0)
         noise = noise.to(dev, torch.float32).contiguous()
-        t = torch.as_tensor(t).cpu().long().reshape(-1)
-        out = torch.empty_like(x0)
-        for i in range(x0.shape[0]):
-            out[i] = ops.axpby(x0[i], noise[i], float(sqrt_a[t[i]]), float(sqrt_1m[t[i]]))
-        return out
+        return ops.noise_to_timesteps(x0, noise, t, sqrt_a, sqrt_1m)
 
     @torch.no_grad()
     def decode(self, x_latent, cond, t_start, unconditional_guidance_scale=1.0, unconditional_conditioning=None,

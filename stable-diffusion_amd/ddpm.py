@@ -38,7 +38,9 @@ def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2,
 class LatentDiffusion:
     """Inference-side stand-in for stable_diffusion.LatentDiffusion.
 
-    Accepts the scripts' parameter dictionaries (txt2img.py:14-42).  ``cond_stage_config`` is not
+    Accepts the scripts' parameter dictionaries (txt2img.py:14-42) plus ``compute_dtype`` ("fp16" / "bf16" fast
+    path, "fp32" parity mode; default: what ``unet_config['use_fp16']`` selects, i.e. fp32 for the scripts'
+    dictionaries).  ``cond_stage_config`` is not
     instantiated: the text encoder lives in a third-party package and the conditioning enters this
     path as a tensor (see ``get_learned_conditioning``).
     """
@@ -46,7 +48,7 @@ class LatentDiffusion:
     def __init__(self, first_stage_config, cond_stage_config=None, unet_config=None, linear_start=1e-4,
                  linear_end=2e-2, cosine_s=8e-3, timesteps=1000, beta_schedule="linear", scale_factor=1.0,
                  conditioning_key=None, concat_mode=True, parameterization="eps", v_posterior=0.,
-                 given_betas=None, compute_dtype="fp16", device=None, log_every_t=100, image_size=256, channels=3,
+                 given_betas=None, compute_dtype=None, device=None, log_every_t=100, image_size=256, channels=3,
                  **ignored):
         assert parameterization in ["eps", "x0"], 'currently only supporting "eps" and "x0"'
         if conditioning_key is None:
@@ -60,6 +62,9 @@ class LatentDiffusion:
         self.image_size, self.channels = image_size, channels
         self.clip_denoised = False      # LatentDiffusion overrides DDPM's default (:4089)
         self.device = torch.device(device if device is not None else "cuda")
+        # not given: the reference's switch decides (unet_config's use_fp16, default False -> fp32 numerics)
+        if compute_dtype is None:
+            compute_dtype = "fp16" if (unet_config or {}).get("use_fp16", False) else "fp32"
         self.compute_dtype = compute_dtype
         self.model = DiffusionWrapper(unet_config, conditioning_key, compute_dtype=compute_dtype, device=self.device)
         self.first_stage_model = AutoencoderKL(**{k: v for k, v in first_stage_config.items() if k != "monitor"},
@@ -174,12 +179,7 @@ class LatentDiffusion:
         if noise is None:
             noise = torch.randn_like(x_start)
         noise = noise.to(self.device, torch.float32).contiguous()
-        t = torch.as_tensor(t).cpu().long()
-        out = torch.empty_like(x_start)
-        for i in range(x_start.shape[0]):
-            out[i] = ops.axpby(x_start[i], noise[i], float(self.sqrt_alphas_cumprod[t[i]]),
-                               float(self.sqrt_one_minus_alphas_cumprod[t[i]]))
-        return out
+        return ops.noise_to_timesteps(x_start, noise, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
 
     # ---- ancestral (DDPM) sampling -------------------------------------------------------------------
     def _uniform_t(self, t, b):
@@ -235,15 +235,16 @@ class LatentDiffusion:
     @torch.no_grad()
     def p_sample(self, x, c, t, clip_denoised=False, repeat_noise=False, return_codebook_ids=False,
                  quantize_denoised=False, return_x0=False, temperature=1., noise_dropout=0., score_corrector=None,
-                 corrector_kwargs=None, noise=None):
+                 corrector_kwargs=None, noise=None, _eps_out=None):
         """stable_diffusion.py:4693-4721.  One UNet call and one fused update kernel; ``noise`` may be
-        injected (the reference draws it with torch.randn)."""
+        injected (the reference draws it with torch.randn); ``_eps_out`` names the UNet's output buffer (the
+        sampling loops keep it, x and t at fixed addresses so that the UNet's launch graph is replayed)."""
         if return_codebook_ids or quantize_denoised:
             raise NotImplementedError("VQ first stage options are not on this path")
         x = x.to(self.device, torch.float32).contiguous()
         b = x.shape[0]
         tt = self._uniform_t(t, b)
-        model_out = self.apply_model(x, torch.as_tensor(t).to(self.device), c)
+        model_out = self.apply_model(x, torch.as_tensor(t).to(self.device), c, out=_eps_out)
         if score_corrector is not None:
             assert self.parameterization == "eps"
             model_out = score_corrector.modify_score(self, model_out, x, t, c, **(corrector_kwargs or {}))
@@ -274,21 +275,32 @@ class LatentDiffusion:
         update per step (``step_fn`` returns the new latent and what to log), optional known-region blend."""
         b = img.shape[0]
         unet = self.model.diffusion_model
-        unet.set_uniform_timesteps(True)          # one timestep for the whole batch in every call below
-        try:
-            for i in range(steps - 1, -1, -1):
-                ts = torch.full((b,), i, device=self.device, dtype=torch.long)
-                img, logged = step_fn(img, cond, ts, i)
-                if mask is not None:
-                    img = self.q_sample(x0, ts) * mask + (1. - mask) * img
-                if i % log_every_t == 0 or i == steps - 1:
-                    keep.append(logged if logged is not None else img)
-                if callback:
-                    callback(i)
-                if img_callback:
-                    img_callback(img, i)
-        finally:
-            unet.set_uniform_timesteps(False)
+        # x, t and eps live at fixed addresses for the whole loop: the UNet replays its captured launch graph
+        # instead of recording a new one per step
+        xbuf = img.to(self.device, torch.float32).clone().contiguous()
+        ts = torch.empty((b,), device=self.device, dtype=torch.long)
+        ebuf = torch.empty_like(xbuf)
+        if mask is not None:
+            x0_d = x0.to(self.device, torch.float32).contiguous()
+            m_d = mask.to(self.device, torch.float32).expand(b, -1, -1, -1).contiguous()
+        for i in range(steps - 1, -1, -1):
+            ts.fill_(i)
+            unet.set_uniform_timesteps(True)      # one timestep for the whole batch; off again before callbacks run
+            try:
+                img, logged = step_fn(xbuf, cond, ts, i, ebuf)
+            finally:
+                unet.set_uniform_timesteps(False)
+            if mask is not None:
+                # img = q_sample(x0, ts) * mask + (1 - mask) * img  (:4822-4824), one kernel
+                img = ops.q_sample_blend(x0_d, torch.randn_like(x0_d), m_d, img.contiguous(),
+                                         self.sqrt_alphas_cumprod[i], self.sqrt_one_minus_alphas_cumprod[i])
+            if i % log_every_t == 0 or i == steps - 1:
+                keep.append(logged if logged is not None else img)
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(img, i)
+            xbuf.copy_(img)
         return img
 
     @torch.no_grad()
@@ -304,8 +316,8 @@ class LatentDiffusion:
             assert x0 is not None
             assert x0.shape[2:3] == mask.shape[2:3]  # spatial size has to match
         intermediates = [img]
-        step = lambda im, c, ts, i: (self.p_sample(im, c, ts, clip_denoised=self.clip_denoised,
-                                                   quantize_denoised=quantize_denoised), None)
+        step = lambda im, c, ts, i, ebuf: (self.p_sample(im, c, ts, clip_denoised=self.clip_denoised,
+                                                         quantize_denoised=quantize_denoised, _eps_out=ebuf), None)
         img = self._ancestral_loop(cond, img, steps, step, intermediates, log_every_t or self.log_every_t, mask, x0,
                                    callback, img_callback)
         return (img, intermediates) if return_intermediates else img
@@ -326,10 +338,11 @@ class LatentDiffusion:
         if mask is not None:
             assert x0 is not None
         x0_log = []
-        step = lambda im, c, ts, i: self.p_sample(im, c, ts, clip_denoised=self.clip_denoised,
-                                                  quantize_denoised=quantize_denoised, return_x0=True,
-                                                  temperature=temps[i], noise_dropout=noise_dropout,
-                                                  score_corrector=score_corrector, corrector_kwargs=corrector_kwargs)
+        step = lambda im, c, ts, i, ebuf: self.p_sample(im, c, ts, clip_denoised=self.clip_denoised,
+                                                        quantize_denoised=quantize_denoised, return_x0=True,
+                                                        temperature=temps[i], noise_dropout=noise_dropout,
+                                                        score_corrector=score_corrector,
+                                                        corrector_kwargs=corrector_kwargs, _eps_out=ebuf)
         img = self._ancestral_loop(self._first_n(cond, b), img, steps, step, x0_log, log_every_t or self.log_every_t,
                                    mask, x0, callback, img_callback)
         return img, x0_log

@@ -159,10 +159,45 @@ def ddpm_step(x, eps, sqrt_recip_acp, sqrt_recipm1_acp, coef1, coef2, noise_coef
     return x_prev, pred
 
 
-def axpby(a, b, ca, cb):
+def axpby(a, b, ca, cb, out=None):
     a, b = _f32(a), _f32(b)
-    out = torch.empty_like(a)
+    out = torch.empty_like(a) if out is None else _f32(out)
     check(_lib.lib().sdmi_axpby(ptr(a), ptr(b), float(ca), float(cb), ptr(out), a.numel(), stream_ptr()), "axpby")
+    return out
+
+
+def noise_to_timesteps(x0, noise, t, table_a, table_b):
+    """table_a[t] * x0 + table_b[t] * noise with per-sample table indices ``t`` (extract_into_tensor semantics,
+    stable_diffusion.py:3600-3603: a one-element ``t`` serves every sample).  One launch per run of equal
+    indices, so the usual case of one timestep for the whole batch is a single launch."""
+    x0, noise = _f32(x0), _f32(noise)
+    b = x0.shape[0]
+    t = torch.as_tensor(t).reshape(-1).cpu().long()
+    if t.numel() == 1:
+        t = t.expand(b)
+    assert t.numel() == b, f"{t.numel()} timesteps for a batch of {b}"
+    out = torch.empty_like(x0)
+    lo = 0
+    while lo < b:
+        hi = lo + 1
+        while hi < b and t[hi] == t[lo]:
+            hi += 1
+        axpby(x0[lo:hi], noise[lo:hi], float(table_a[t[lo]]), float(table_b[t[lo]]), out=out[lo:hi])
+        lo = hi
+    return out
+
+
+def q_sample_blend(x0, noise, mask, img, sqrt_acp, sqrt_one_minus_acp, out=None):
+    """(sqrt_acp * x0 + sqrt_one_minus_acp * noise) * mask + (1 - mask) * img: the DDIM loop's known-region blend
+    (one timestep for the batch); mask (B,1,H,W) or (B,C,H,W).  ``out`` may be ``img``."""
+    x0, noise, mask, img = _f32(x0), _f32(noise), _f32(mask), _f32(img)
+    b, c, h, w = x0.shape
+    assert noise.shape == x0.shape and img.shape == x0.shape
+    assert mask.dim() == 4 and mask.shape[0] == b and tuple(mask.shape[2:]) == (h, w), f"mask shape {tuple(mask.shape)}"
+    out = torch.empty_like(x0) if out is None else _f32(out)
+    check(_lib.lib().sdmi_q_sample_blend(ptr(x0), ptr(noise), ptr(mask), ptr(img), float(sqrt_acp),
+                                         float(sqrt_one_minus_acp), ptr(out), b, c, h * w, mask.shape[1],
+                                         stream_ptr()), "q_sample_blend")
     return out
 
 

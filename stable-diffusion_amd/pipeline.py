@@ -112,7 +112,9 @@ def inpaint(model, image, mask, uc, c, steps=50, scale=7.5, eta=0.0, sampler=Non
     b = image.shape[0]
     dev = model.device
     image, mask = image.to(dev, torch.float32), mask.to(dev, torch.float32)
-    masked_image = (1 - mask) * image                                           # make_batch :66
+    # make_batch (inpaint_with_text.py:65-70) masks the image in [0,1] and then maps both tensors through
+    # * 2 - 1, so repainted pixels become -1: ((1 - m) * (image + 1) / 2) * 2 - 1 = (1 - m) * image - m
+    masked_image = (1 - mask) * image - mask
     pn = posterior_noise if posterior_noise is not None else (None, None)
     img_latent = model.get_first_stage_encoding(model.encode_first_stage(image), noise=pn[0])
     masked_latent = model.get_first_stage_encoding(model.encode_first_stage(masked_image), noise=pn[1])
@@ -134,6 +136,57 @@ def shard(total, rank, world):
     per = (total + world - 1) // world
     lo = min(total, rank * per)
     return lo, min(total, lo + per)
+
+
+def sample_batches(lo, hi, batch):
+    """[(first global sample index, count)] for the block [lo, hi) walked `batch` samples at a time, the way
+    txt2img.py:258-303 walks its prompt list in chunks of n_samples (the last chunk may be short)."""
+    return [(s, min(batch, hi - s)) for s in range(lo, hi, batch)]
+
+
+def run_sample_list(total, batch, run_batch, rank=None, world=None):
+    """A fixed list of `total` samples over the ranks of the process group: this rank takes the contiguous
+    block ``shard(total, rank, world)``, hands it to ``run_batch(first, count) -> (count, ...) tensor`` in
+    chunks of `batch`, and the per-rank results are all-gathered into a (total, ...) tensor that every
+    rank receives, in global sample order.  ``run_batch`` must derive everything from the global sample
+    index, so the result does not depend on the number of ranks."""
+    import torch.distributed as dist
+    live = dist.is_available() and dist.is_initialized()
+    if world is None:
+        world = dist.get_world_size() if live else 1
+    if rank is None:
+        rank = dist.get_rank() if live else 0
+    lo, hi = shard(total, rank, world)
+    parts = [run_batch(first, n) for first, n in sample_batches(lo, hi, batch)]
+    return gather_sharded(parts, total, rank, world)
+
+
+def gather_sharded(parts, total, rank, world):
+    """Concatenate this rank's batch results and all-gather the (possibly ragged: total need not divide by
+    world, trailing ranks may own nothing) per-rank blocks into one (total, ...) tensor."""
+    per = (total + world - 1) // world
+    lo, hi = shard(total, rank, world)
+    if world == 1:
+        return torch.cat(parts) if len(parts) != 1 else parts[0]
+    import torch.distributed as dist
+    # every rank contributes `per` rows (a short last block is zero-padded; the padding lands behind row `total`)
+    mine = (torch.cat(parts) if len(parts) != 1 else parts[0]) if parts else None
+    if (world - 1) * per >= total:
+        # some rank owns no sample and cannot know the row shape: rank 0 (never empty) announces it
+        kinds = (torch.float32, torch.uint8, torch.float16)
+        meta = [list(mine.shape[1:]) + [kinds.index(mine.dtype), int(mine.is_cuda)] if rank == 0 else None]
+        dist.broadcast_object_list(meta, src=0)
+        tail, dtype, on_gpu = tuple(meta[0][:-2]), kinds[meta[0][-2]], meta[0][-1]
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    else:
+        tail, dtype, dev = tuple(mine.shape[1:]), mine.dtype, mine.device
+    if mine is not None and hi - lo == per:
+        block = mine
+    else:
+        block = torch.zeros((per,) + tail, dtype=dtype, device=dev)
+        if mine is not None:
+            block[:hi - lo] = mine
+    return gather_images(block, world)[:total]
 
 
 def gather_images(img, world=None):

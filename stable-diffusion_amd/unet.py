@@ -56,8 +56,12 @@ def _handle_weight_shapes(h):
 class UNetModel:
     """Drop-in for stable_diffusion.UNetModel (inference only).
 
-    Same kwargs as stable_diffusion.py:3263-3286; one extra, ``compute_dtype`` ("fp16" default,
-    "bf16", or "fp32" for the parity mode; the reference's ``use_fp16=True`` selects "fp16").
+    Same kwargs as stable_diffusion.py:3263-3286; one extra, ``compute_dtype``: "fp16" / "bf16" (MFMA
+    operands in 16 bits, fp32 accumulation: the fast path, within 2e-2 of the reference per call) or "fp32"
+    (parity mode, within 1e-4).  When it is not given the reference's own switch decides, as it does there
+    (:3302: ``self.dtype = th.float16 if use_fp16 else th.float32``): ``use_fp16=True`` selects "fp16", the
+    default ``use_fp16=False`` selects "fp32", so a caller that swaps the class in keeps fp32 numerics until
+    it asks for the fast path.
     Weights arrive through ``load_state_dict`` with the reference's keys and layouts.
     """
 
@@ -81,7 +85,7 @@ class UNetModel:
         self.model_channels = model_channels
         self.out_channels = out_channels
         self.num_classes = num_classes
-        self.compute_dtype = compute_dtype or ("fp16" if use_fp16 else "fp16")
+        self.compute_dtype = compute_dtype or ("fp16" if use_fp16 else "fp32")
         self.dtype = torch.float32          # boundary dtype: x and eps are fp32 NCHW like the reference
         self.device = torch.device(device if device is not None else "cuda")
         self._h = _create_handle(self.config, self.compute_dtype)
@@ -177,6 +181,31 @@ class UNetModel:
         return out
 
     __call__ = forward
+
+    def run_block(self, kind, index, x, emb=None, skip=None, context=None):
+        """One ResBlock (``kind`` "res": ResBlock.forward(x, emb), stable_diffusion.py:3197) or SpatialTransformer
+        ("st": forward(x, context), :2885) of this model on its own, through the executor's code for it.  x / skip:
+        NHWC tensors in the compute dtype; emb: fp32 (B, 4 * model_channels); returns NHWC."""
+        if not self._finalized:
+            raise RuntimeError("UNetModel.run_block called before load_state_dict")
+        if context is not None and (context is not self._ctx_ref or context._version != self._ctx_version):
+            self.set_context(context)
+        b, h, w, _ = x.shape
+        shapes = list(self._shapes.items())
+        if kind == "res":
+            names = [k for k, _ in shapes if k.endswith(".in_layers.2.weight")]
+            cout = self._shapes[names[index]][0]
+        else:
+            names = [k for k, _ in shapes if k.endswith(".proj_out.weight")]
+            cout = self._shapes[names[index]][0]
+        x = x.contiguous()
+        out = torch.empty((b, h, w, cout), dtype=x.dtype, device=x.device)
+        skip = None if skip is None else skip.contiguous()
+        emb = None if emb is None else emb.to(self.device, torch.float32).contiguous()
+        check(_lib.lib().sdmi_unet_run_block(self._h, 0 if kind == "res" else 1, index, ptr(x), ptr(skip),
+                                             0 if skip is None else skip.shape[-1], ptr(emb), ptr(out), b, h, w,
+                                             stream_ptr()), "unet_run_block")
+        return out
 
     def __del__(self):
         try:

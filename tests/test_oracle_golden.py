@@ -130,6 +130,25 @@ def test_g5_sampler_kat():
     assert torch.equal(qs, g["q_sample.t981_1"])
 
 
+def test_g13_known_region_blend():
+    """sample(mask=, x0=): the blend the oracle restates equals what the reference handed to p_sample_ddim at the
+    first step bit for bit, and the 4-step trajectory driven by the oracle UNet ends on the reference's latent."""
+    from oracle import unet_ref
+    g = golden("g13_mask_blend")
+    tab = sampler_ref.ddpm_tables()
+    ts = sampler_ref.ddim_tables(tab["alphas_cumprod"], 4, 0.0)["timesteps"]
+    t = torch.full((1,), int(ts[-1]), dtype=torch.long)
+    first = sampler_ref.known_region_blend(g["x0"], t, tab, g["q_noise"][0], g["mask"], g["x_T"])
+    assert torch.equal(first, g["blended"][0])
+    ust = S.unet_structure(**S.sd_v1_unet_config(4))
+    usd = synth.synth_state_dict(S.unet_param_shapes(ust), 0)
+    ctx = torch.cat([g["uc"].float(), g["c"].float()])
+    torch.set_num_threads(8)
+    z = sampler_ref.ddim_loop(lambda xi, ti: unet_ref.unet_forward(usd, ust, xi, ti, ctx), g["x_T"], 4, 0.0, 7.5, tab,
+                              mask=g["mask"], x0=g["x0"], q_noises=list(g["q_noise"]))
+    assert max_rel_err(z, g["z"]) < 2e-5
+
+
 def test_g11_ddpm_kat():
     """The ancestral update restated in the oracle equals LatentDiffusion.p_sample bit for bit."""
     g = golden("g11_ddpm_kat")

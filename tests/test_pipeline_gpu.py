@@ -177,6 +177,59 @@ def test_img2img_pipeline_against_oracle(dt):
 
 
 @pytest.mark.parametrize("dt", ["fp32", "fp16"])
+def test_inpaint_pipeline_against_oracle(dt):
+    """pipeline.inpaint (inpaint_with_text.py:51-70 make_batch, :251-291: encode image and masked image ->
+    stochastic_encode at t = S-1 -> hybrid 9-channel sample() with CFG -> decode -> composite) against the CPU
+    oracle composing the same calls, 128x128, 4 steps.  The masked image is formed in [0,1] and then mapped to
+    [-1,1] as make_batch does, so repainted pixels enter the encoder as -1."""
+    from oracle import unet_ref, sampler_ref, vae_ref
+    from _util import structure as S, synth
+    pipeline = importlib.import_module("stable-diffusion_amd.pipeline")
+    model = device_latent_diffusion(9, "hybrid", dt)
+    image01 = synth.uniform(61, "inp.image", (1, 3, 128, 128), 0.0, 1.0)
+    mask = torch.zeros(1, 1, 128, 128)
+    mask[:, :, 24:88, 40:120] = 1.0
+    pn = (synth.normal(62, "inp.pn0", (1, 4, 16, 16)), synth.normal(63, "inp.pn1", (1, 4, 16, 16)))
+    noise = synth.normal(64, "inp.noise", (1, 4, 16, 16))
+    uc = synth.normal(2, "uncond_ctx", (1, 77, 768)).half().float()
+    c = synth.normal(1, "cond_ctx.0", (1, 77, 768)).half().float()
+    steps, scale = 4, 7.5
+    image = image01 * 2.0 - 1.0
+    out, z = pipeline.inpaint(model, image.cuda(), mask.cuda(), uc.cuda(), c.cuda(), steps=steps, scale=scale,
+                              noise=noise.cuda(), posterior_noise=(pn[0].cuda(), pn[1].cuda()))
+    torch.cuda.synchronize()
+    # oracle: make_batch
+    masked = ((1 - mask) * image01) * 2.0 - 1.0
+    assert float(masked[:, :, 30, 50].max()) == -1.0
+    torch.set_num_threads(16)
+    est = S.vae_encoder_structure(S.sd_v1_ddconfig(), 4)
+    dst = S.vae_decoder_structure(S.sd_v1_ddconfig(), 4)
+    vsd = synth.synth_state_dict(S.vae_encoder_param_shapes(est), 0)
+    vsd.update(synth.synth_state_dict(S.vae_decoder_param_shapes(dst), 0))
+    ust = S.unet_structure(**S.sd_v1_unet_config(9))
+    usd = synth.synth_state_dict(S.unet_param_shapes(ust), 0)
+    img_latent = vae_ref.get_first_stage_encoding(vae_ref.encode(vsd, est, image), pn[0])
+    masked_latent = vae_ref.get_first_stage_encoding(vae_ref.encode(vsd, est, masked), pn[1])
+    img_mask = torch.nn.functional.interpolate(mask, size=img_latent.shape[-2:])
+    ddpm = sampler_ref.ddpm_tables()
+    tab = sampler_ref.ddim_tables(ddpm["alphas_cumprod"], steps, 0.0)
+    x_T = sampler_ref.stochastic_encode(img_latent, torch.tensor([steps - 1]), tab, noise)
+    cond = {"c_concat": [[torch.cat([img_mask] * 2)], [torch.cat([masked_latent] * 2)]],
+            "c_crossattn": [torch.cat([uc, c])]}
+    z_ref = sampler_ref.ddim_loop(lambda xi, ti: unet_ref.apply_model(usd, ust, "hybrid", xi, ti, cond), x_T, steps, 0.0,
+                                  scale, ddpm)
+    pred = vae_ref.to_image(vae_ref.decode_first_stage(vsd, dst, z_ref))
+    out_ref = (1 - mask) * vae_ref.to_image(image) + mask * pred
+    e_z, p = max_rel_err(z.cpu(), z_ref), psnr(out.cpu(), out_ref)
+    print(f"inpaint pipeline {dt}: latent {e_z:.3e}, image PSNR {p:.1f} dB")
+    assert tuple(out.shape) == (1, 3, 128, 128)
+    assert e_z < (5e-4 if dt == "fp32" else 5e-2) and p > (60 if dt == "fp32" else 35)
+    # the kept region is the input image itself
+    keep = (mask == 0).expand_as(out_ref)
+    assert torch.equal(out.cpu()[keep], vae_ref.to_image(image)[keep])
+
+
+@pytest.mark.parametrize("dt", ["fp32", "fp16"])
 def test_g9_img2img(dt):
     """stochastic_encode at strength 0.75 (t_enc = 37 of 50) then decode() with CFG 5.0."""
     model = device_latent_diffusion(4, "crossattn", dt)

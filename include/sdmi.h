@@ -237,6 +237,16 @@ int64_t sdmi_groupnorm_scratch_bytes(int batch, int groups);
 int sdmi_groupnorm(const void* x0, int c0, const void* x1, int c1, int batch, int hw, int groups, float eps,
                    const float* gamma, const float* beta, int silu, void* out, void* scratch, int dtype,
                    void* stream);
+/* sdmi_groupnorm for callers that cannot allocate or bring a workspace: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments and the
+ * same results bit for bit, minus `scratch`: the partial sums the two launches exchange live in a buffer
+ * built into the library (a device array of 2 MiB + 8 KiB, one copy per GPU, held until the process ends),
+ * which limits a call to batch <= 32 and groups <= 32; larger calls fail with SDMI_EINVAL and a message.
+ * The call makes no hipMalloc / hipFree and calls no allocating routine.  All calls on one GPU share that
+ * GPU's buffer: calls that overlap in time on one GPU (different streams) race; calls on one stream are safe.
+ * Nothing in the buffer needs clearing between calls (the first launch writes every word the second reads). */
+int sdmi_groupnorm_static(const void* x0, int c0, const void* x1, int c1, int batch, int hw, int groups, float eps,
+                          const float* gamma, const float* beta, int silu, void* out, int dtype, void* stream);
 /* nn.LayerNorm (:2807-2809) over the last dim */
 int sdmi_layernorm(const void* x, void* out, const float* gamma, const float* beta, int rows, int d, float eps,
                    int dtype, void* stream);

@@ -91,6 +91,8 @@ SIGNATURES = {
     "sdmi_groupnorm_scratch_bytes": (c_int64, [c_int, c_int]),
     "sdmi_groupnorm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "sdmi_groupnorm_static": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
+                                      c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "sdmi_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
     "sdmi_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sdmi_pack_geglu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

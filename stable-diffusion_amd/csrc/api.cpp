@@ -172,6 +172,14 @@ int sdmi_groupnorm(const void* x0, int c0, const void* x1, int c1, int batch, in
   return groupnorm(a, (hipStream_t)stream);
 }
 
+int sdmi_groupnorm_static(const void* x0, int c0, const void* x1, int c1, int batch, int hw, int groups, float eps,
+                          const float* gamma, const float* beta, int silu, void* out, int dtype, void* stream) {
+  GroupNormArgs a;
+  a.x0 = x0; a.c0 = c0; a.x1 = x1; a.c1 = c1; a.B = batch; a.HW = hw; a.groups = groups; a.eps = eps;
+  a.gamma = gamma; a.beta = beta; a.silu = silu; a.out = out; a.dtype = dtype;
+  return groupnorm_static(a, (hipStream_t)stream);
+}
+
 int sdmi_layernorm(const void* x, void* out, const float* gamma, const float* beta, int rows, int d, float eps,
                    int dtype, void* stream) {
   return layernorm(x, out, gamma, beta, rows, d, eps, dtype, (hipStream_t)stream);

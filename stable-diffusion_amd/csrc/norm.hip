@@ -14,6 +14,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 namespace {
 
 constexpr int GN_MAX_CHUNKS = 256;
@@ -369,6 +371,52 @@ int launch_ln(const void* x, void* out, const float* gamma, const float* beta, i
 }
 
 }  // namespace
+
+// ---- GroupNorm for callers that cannot allocate -----------------------------------------------------
+// The two GroupNorm launches hand the per-strip partial sums to each other through a scratch buffer that
+// sdmi_groupnorm takes from its caller.  The variant below owns that buffer instead: a file-scope device
+// array, one copy per GPU at that GPU's own address, held until the process ends.  In host code the
+// array's name is only a handle for hipGetSymbolAddress; everything that touches the memory (the kernel
+// argument) uses the address that call returned for the current device.
+constexpr int GN_STATIC_MAX_BATCH = 32;
+constexpr int GN_STATIC_MAX_GROUPS = 32;
+constexpr size_t GN_STATIC_FLOATS =
+    (size_t)GN_STATIC_MAX_BATCH * GN_MAX_CHUNKS * GN_STATIC_MAX_GROUPS * 2 + (size_t)GN_STATIC_MAX_BATCH * GN_STATIC_MAX_GROUPS * 2;
+static __device__ __align__(256) float scratch[GN_STATIC_FLOATS];      // 2 MiB + 8 KiB
+
+namespace {
+constexpr int GN_MAX_DEVICES = 64;
+float* g_gn_static_ptr[GN_MAX_DEVICES];          // device address of `scratch` on each GPU, resolved on first use
+std::mutex g_gn_static_mu;
+}  // namespace
+
+int groupnorm_static(const GroupNormArgs& a_in, hipStream_t stream) {
+  SDMI_REQUIRE(a_in.B > 0 && a_in.B <= GN_STATIC_MAX_BATCH,
+               "groupnorm_static: batch %d is beyond the built-in scratch (at most %d samples per call; use "
+               "sdmi_groupnorm with a caller-provided scratch buffer for more)", a_in.B, GN_STATIC_MAX_BATCH);
+  SDMI_REQUIRE(a_in.groups > 0 && a_in.groups <= GN_STATIC_MAX_GROUPS,
+               "groupnorm_static: %d groups are beyond the built-in scratch (at most %d)", a_in.groups,
+               GN_STATIC_MAX_GROUPS);
+  SDMI_REQUIRE(groupnorm_scratch_floats(a_in.B, a_in.HW, a_in.groups) <= GN_STATIC_FLOATS,
+               "groupnorm_static: the call needs more scratch than is built in");
+  int dev = -1;
+  SDMI_CHECK_HIP(hipGetDevice(&dev));
+  SDMI_REQUIRE(dev >= 0 && dev < GN_MAX_DEVICES, "groupnorm_static: device ordinal %d not supported", dev);
+  float* ptr;
+  {
+    std::lock_guard<std::mutex> lock(g_gn_static_mu);
+    if (!g_gn_static_ptr[dev]) {
+      void* sym = nullptr;
+      SDMI_CHECK_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)));     // this device's copy of the array
+      SDMI_REQUIRE(sym != nullptr, "groupnorm_static: the scratch symbol has no address on device %d", dev);
+      g_gn_static_ptr[dev] = (float*)sym;
+    }
+    ptr = g_gn_static_ptr[dev];
+  }
+  GroupNormArgs a = a_in;
+  a.scratch = ptr;      // every partial sum the second launch reads is written by the first: nothing to clear
+  return groupnorm(a, stream);
+}
 
 size_t groupnorm_scratch_floats(int B, int HW, int groups) {
   (void)HW;

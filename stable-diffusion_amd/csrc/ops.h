@@ -71,6 +71,8 @@ struct GroupNormArgs {
 };
 size_t groupnorm_scratch_floats(int B, int HW, int groups);
 int groupnorm(const GroupNormArgs& a, hipStream_t stream);
+// same, with the library's built-in per-GPU scratch (a.scratch is ignored); allocates nothing
+int groupnorm_static(const GroupNormArgs& a, hipStream_t stream);
 
 int layernorm(const void* x, void* out, const float* gamma, const float* beta, int rows, int d,
               float eps, int dtype, hipStream_t stream);

@@ -262,6 +262,17 @@ int sdmi_conv2d(const void* a0, int c0, const void* a1, int c1, const void* w, c
                 const float* rowadd, const void* resid, int ldr, void* out, int ldo, int batch, int hin,
                 int win, int taps, int stride, int pad_lo, int up, int n_out, int geglu, int splits,
                 void* partial, int dtype, void* stream);
+/* The convolutions on the NCHW fp32 boundary.  conv_in: the first 3x3 convolution of the UNet (input_blocks.0.0,
+ * :3328-3331; with the hybrid concat of DiffusionWrapper :3656 folded in) and of the VAE (conv_in :363, :468):
+ * src[i] fp32 NCHW [batch][channels[i]][h][w], channel-concatenated in order (n_src <= 3, at most 64 channels in
+ * all); w fp32 OIHW [cout][cin][3][3]; out NHWC [batch][h][w][cout] in dtype.  conv_out: the last 3x3 convolution
+ * (out.2 :3491-3495, conv_out :413, :522): x NHWC in dtype, out fp32 NCHW [batch][cout][h][w], cout in
+ * {3, 4, 8} (any cout <= 16 when cin is 128 or 320).  wpack: fp32 scratch of 9 * cin * cout floats (the
+ * handles pack once at load). */
+int sdmi_conv_in(const void* const* src, const int* channels, int n_src, const float* w, const float* bias,
+                 float* wpack, void* out, int batch, int h, int width, int cout, int dtype, void* stream);
+int sdmi_conv_out(const void* x, const float* w, const float* bias, float* wpack, float* out, int batch, int h,
+                  int width, int cin, int cout, int dtype, void* stream);
 /* Split count the UNet executor uses for an (m x k) * (k x n) problem of this dtype (1 = no split);
  * callers that want the executor's schedule size `partial` from it.  No counterpart in the reference. */
 int sdmi_conv2d_splits(int m, int n, int k, int dtype);

@@ -99,6 +99,10 @@ SIGNATURES = {
     "sdmi_conv2d": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                             c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                             c_void_p, c_int, c_void_p]),
+    "sdmi_conv_in": (c_int, [P(c_void_p), P(c_int), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                             c_int, c_int, c_void_p]),
+    "sdmi_conv_out": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                              c_int, c_void_p]),
     "sdmi_conv2d_splits": (c_int, [c_int, c_int, c_int, c_int]),
     "sdmi_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),

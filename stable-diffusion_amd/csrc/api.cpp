@@ -212,6 +212,24 @@ int sdmi_conv2d(const void* a0, int c0, const void* a1, int c1, const void* w, c
 
 int sdmi_conv2d_splits(int m, int n, int k, int dtype) { return conv_gemm_pick_splits(m, n, k, dtype); }
 
+int sdmi_conv_in(const void* const* src, const int* channels, int n_src, const float* w, const float* bias,
+                 float* wpack, void* out, int batch, int h, int width, int cout, int dtype, void* stream) {
+  SDMI_REQUIRE(src && channels && n_src >= 1 && n_src <= 3 && w && bias && wpack && out, "conv_in: bad arguments");
+  InConvArgs a;
+  int cin = 0;
+  for (int i = 0; i < n_src; ++i) { a.src[i] = (const float*)src[i]; a.c[i] = channels[i]; cin += channels[i]; }
+  SDMI_TRY(pack_inconv_weight(w, wpack, cout, cin, (hipStream_t)stream));
+  a.w = wpack; a.bias = bias; a.out = out; a.B = batch; a.H = h; a.W = width; a.Cout = cout; a.dtype = dtype;
+  return in_conv(a, (hipStream_t)stream);
+}
+
+int sdmi_conv_out(const void* x, const float* w, const float* bias, float* wpack, float* out, int batch, int h,
+                  int width, int cin, int cout, int dtype, void* stream) {
+  SDMI_REQUIRE(x && w && bias && wpack && out, "conv_out: null pointer");
+  SDMI_TRY(pack_outconv_weight(w, wpack, cout, cin, (hipStream_t)stream));
+  return out_conv(x, wpack, bias, out, batch, h, width, cin, cout, dtype, (hipStream_t)stream);
+}
+
 int sdmi_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
                    int batch, int heads, int nq, int nk, int d, float scale, int dtype, int impl, void* stream) {
   AttentionArgs a;

@@ -1,5 +1,4 @@
-// Small and elementwise gfx950 kernels of the denoising path: timestep embedding, tiny-M linears,
-// the first and last convolutions (NCHW fp32 boundary <-> NHWC internal layout), the fused
+// Small and elementwise gfx950 kernels of the denoising path: timestep embedding, tiny-M linears, the fused
 // classifier-free-guidance + DDIM update, row softmax, image post-scale and weight packing.
 #include "ops.h"
 #include <math.h>
@@ -85,107 +84,6 @@ __global__ __launch_bounds__(SL_THREADS) void small_linear_kernel(const float* x
           y[(size_t)(mb + m) * N + n0 + j] = v;
         }
       }
-  }
-}
-
-// ---- first convolution ---------------------------------------------------------------------------
-struct InConvParams {
-  const float* src[3]; int c[3]; int Cin;
-  const float* w; const float* bias; void* out;
-  int B, H, W, Cout;
-};
-
-// A thread owns 8 consecutive output channels of one pixel and a workgroup walks pixels with the
-// whole [9 Cin][Cout] fp32 weight block parked in LDS (46 KiB for 4 -> 320): the 36 input values of a
-// pixel are read once per thread (broadcast across the pixel's threads), every weight comes from LDS
-// as 2 x 16 bytes per 8 FMAs, and the store is 16 bytes per thread, 640 contiguous bytes per pixel.
-// Summation order per output: bias, then taps in order, sources in order, channels in order.
-template <typename T>
-__global__ __launch_bounds__(256) void in_conv_kernel(InConvParams p) {
-  extern __shared__ __attribute__((aligned(16))) float in_conv_w[];
-  const int tid = threadIdx.x;
-  const int nw = 9 * p.Cin * p.Cout;
-  for (int i = tid * 4; i < nw; i += 256 * 4)
-    *reinterpret_cast<float4*>(in_conv_w + i) = *reinterpret_cast<const float4*>(p.w + i);
-  __syncthreads();
-  const int tpp = p.Cout / 8;                 // threads per pixel
-  const int ppb = 256 / tpp;                  // pixels per workgroup pass
-  const int tp = tid % tpp, pl = tid / tpp;
-  if (pl >= ppb) return;
-  const int co = tp * 8;
-  float bias[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias[e] = p.bias[co + e];
-  const size_t npix = (size_t)p.B * p.H * p.W;
-  const size_t hw = (size_t)p.H * p.W;
-  for (size_t pix = (size_t)blockIdx.x * ppb + pl; pix < npix; pix += (size_t)gridDim.x * ppb) {
-    const int x = (int)(pix % p.W), y = (int)((pix / p.W) % p.H), b = (int)(pix / hw);
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = bias[e];
-    for (int tap = 0; tap < 9; ++tap) {
-      const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
-      if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W) continue;
-      int cbase = 0;
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        if (p.c[s] == 0) continue;
-        const float* sp = p.src[s] + ((size_t)b * p.c[s] * p.H + iy) * p.W + ix;
-        for (int ci = 0; ci < p.c[s]; ++ci) {
-          const float xv = sp[(size_t)ci * hw];
-          const float* wr = in_conv_w + (size_t)(tap * p.Cin + cbase + ci) * p.Cout + co;
-          const float4 w0 = *reinterpret_cast<const float4*>(wr), w1 = *reinterpret_cast<const float4*>(wr + 4);
-          acc[0] += xv * w0.x; acc[1] += xv * w0.y; acc[2] += xv * w0.z; acc[3] += xv * w0.w;
-          acc[4] += xv * w1.x; acc[5] += xv * w1.y; acc[6] += xv * w1.z; acc[7] += xv * w1.w;
-        }
-        cbase += p.c[s];
-      }
-    }
-    typedef T Tx8 __attribute__((ext_vector_type(8)));
-    if constexpr (sizeof(T) == 2) {
-      Tx8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(acc[e]);
-      *reinterpret_cast<Tx8*>((T*)p.out + pix * p.Cout + co) = o;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ((T*)p.out)[pix * p.Cout + co + e] = from_f32<T>(acc[e]);
-    }
-  }
-}
-
-// ---- last convolution: one wave per output pixel ------------------------------------------------
-template <typename T, int COUT>
-__global__ __launch_bounds__(256) void out_conv_kernel(const T* x, const float* w, const float* bias, float* out,
-                                                       int B, int H, int W, int Cin) {
-  constexpr int EPV = VecOf<T>::N;
-  typedef typename VecOf<T>::type V;
-  const int lane = threadIdx.x & 63;
-  const size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pix >= (size_t)B * H * W) return;
-  const int xx = (int)(pix % W), yy = (int)((pix / W) % H), b = (int)(pix / ((size_t)W * H));
-  float acc[COUT];
-#pragma unroll
-  for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
-  const int nvec = Cin / EPV;
-  for (int tap = 0; tap < 9; ++tap) {
-    const int iy = yy + tap / 3 - 1, ix = xx + tap % 3 - 1;
-    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-    const T* xp = x + (((size_t)b * H + iy) * W + ix) * Cin;
-    for (int v = lane; v < nvec; v += 64) {
-      const V xv = *reinterpret_cast<const V*>(xp + v * EPV);
-#pragma unroll
-      for (int o = 0; o < COUT; ++o) {
-        const float* wp = w + ((size_t)o * 9 + tap) * Cin + v * EPV;
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) acc[o] += to_f32<T>(xv[e]) * wp[e];
-      }
-    }
-  }
-#pragma unroll
-  for (int o = 0; o < COUT; ++o) {
-    const float s = wave_sum(acc[o]);
-    if (lane == 0) out[(((size_t)b * COUT + o) * H + yy) * W + xx] = s + bias[o];
   }
 }
 
@@ -425,18 +323,14 @@ int small_linear(const float* x, const float* W, const float* bias, float* y, in
   return SDMI_OK;
 }
 
-constexpr size_t IN_CONV_MAX_LDS = 144 * 1024;
+int boundary_conv_init();
 
-// Raise the dynamic-LDS limit of the first-convolution kernels once, outside of stream capture.
+// Raise the dynamic-LDS limits of the kernels in this file and of the boundary convolutions once, outside of
+// stream capture.
 int elementwise_init() {
   static bool done = false;
   if (done) return SDMI_OK;
-  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)in_conv_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)IN_CONV_MAX_LDS));
-  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)in_conv_kernel<half_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)IN_CONV_MAX_LDS));
-  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)in_conv_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)IN_CONV_MAX_LDS));
+  SDMI_TRY(boundary_conv_init());
   SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)small_linear_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)SMALL_LINEAR_MAX_LDS));
   SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)small_linear_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -446,55 +340,6 @@ int elementwise_init() {
   SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)small_linear_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)SMALL_LINEAR_MAX_LDS));
   done = true;
-  return SDMI_OK;
-}
-
-int in_conv(const InConvArgs& a, hipStream_t s) {
-  InConvParams p;
-  p.Cin = 0;
-  for (int i = 0; i < 3; ++i) {
-    p.src[i] = a.src[i]; p.c[i] = a.src[i] ? a.c[i] : 0; p.Cin += p.c[i];
-  }
-  SDMI_REQUIRE(a.src[0] && a.w && a.bias && a.out && p.Cin > 0 && p.Cin <= 64, "in_conv: bad arguments");
-  p.w = a.w; p.bias = a.bias; p.out = a.out; p.B = a.B; p.H = a.H; p.W = a.W; p.Cout = a.Cout;
-  SDMI_REQUIRE(a.Cout % 8 == 0 && a.Cout <= 2048, "in_conv: Cout=%d must be a multiple of 8, at most 2048", a.Cout);
-  const size_t lds = (size_t)9 * p.Cin * a.Cout * sizeof(float);
-  SDMI_REQUIRE(lds <= IN_CONV_MAX_LDS, "in_conv: %d x %d weights do not fit in LDS", p.Cin, a.Cout);
-  SDMI_TRY(elementwise_init());
-  const size_t npix = (size_t)a.B * a.H * a.W;
-  const int ppb = 256 / (a.Cout / 8);
-  size_t blocks = (npix + ppb - 1) / ppb;
-  if (blocks > 1024) blocks = 1024;
-  SDMI_DISPATCH_DTYPE(a.dtype, T,
-                      hipLaunchKernelGGL(in_conv_kernel<T>, dim3((unsigned)blocks), dim3(256), lds, s, p));
-  SDMI_CHECK_HIP(hipGetLastError());
-  return SDMI_OK;
-}
-
-template <typename T>
-static int out_conv_t(const void* x, const float* w, const float* bias, float* out, int B, int H, int W,
-                      int Cin, int Cout, hipStream_t s) {
-  const size_t pix = (size_t)B * H * W;
-  dim3 grid((unsigned)((pix + 3) / 4));
-  if (Cout == 4)
-    hipLaunchKernelGGL((out_conv_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)x, w, bias, out, B, H, W, Cin);
-  else if (Cout == 3)
-    hipLaunchKernelGGL((out_conv_kernel<T, 3>), grid, dim3(256), 0, s, (const T*)x, w, bias, out, B, H, W, Cin);
-  else if (Cout == 8)
-    hipLaunchKernelGGL((out_conv_kernel<T, 8>), grid, dim3(256), 0, s, (const T*)x, w, bias, out, B, H, W, Cin);
-  else {
-    sdmi_set_error("out_conv: Cout=%d unsupported (3, 4 or 8)", Cout);
-    return SDMI_EINVAL;
-  }
-  SDMI_CHECK_HIP(hipGetLastError());
-  return SDMI_OK;
-}
-
-int out_conv(const void* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cin,
-             int Cout, int dtype, hipStream_t s) {
-  SDMI_REQUIRE(x && w && bias && out, "out_conv: null pointer");
-  SDMI_REQUIRE(Cin % 8 == 0, "out_conv: Cin must be a multiple of 8");
-  SDMI_DISPATCH_DTYPE(dtype, T, return out_conv_t<T>(x, w, bias, out, B, H, W, Cin, Cout, s));
   return SDMI_OK;
 }
 

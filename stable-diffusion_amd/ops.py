@@ -76,6 +76,38 @@ def conv2d(x, w_packed, bias=None, *, taps=9, stride=1, up=False, x1=None, rowad
     return out
 
 
+def conv_in(sources, w, bias, dtype):
+    """First convolution: fp32 NCHW sources (channel-concatenated) * OIHW fp32 weights -> NHWC in ``dtype``."""
+    import ctypes
+    sources = [_f32(s.contiguous()) for s in sources]
+    w, bias = _f32(w.contiguous()), _f32(bias.contiguous())
+    b, _, h, wd = sources[0].shape
+    cout = w.shape[0]
+    assert w.shape[1] == sum(s.shape[1] for s in sources) and tuple(w.shape[2:]) == (3, 3)
+    out = torch.empty((b, h, wd, cout), dtype=torch_dtype(dtype), device=w.device)
+    wpack = torch.empty((w.numel(),), dtype=torch.float32, device=w.device)
+    n = len(sources)
+    ptrs = (ctypes.c_void_p * n)(*[s.data_ptr() for s in sources])
+    chans = (ctypes.c_int * n)(*[s.shape[1] for s in sources])
+    check(_lib.lib().sdmi_conv_in(ptrs, chans, n, ptr(w), ptr(bias), ptr(wpack), ptr(out), b, h, wd, cout,
+                                  dtype_code(dtype), stream_ptr()), "conv_in")
+    return out
+
+
+def conv_out(x, w, bias):
+    """Last convolution: NHWC activations * OIHW fp32 weights -> fp32 NCHW."""
+    x = x.contiguous()
+    w, bias = _f32(w.contiguous()), _f32(bias.contiguous())
+    b, h, wd, cin = x.shape
+    cout = w.shape[0]
+    assert w.shape[1] == cin and tuple(w.shape[2:]) == (3, 3)
+    out = torch.empty((b, cout, h, wd), dtype=torch.float32, device=x.device)
+    wpack = torch.empty((w.numel(),), dtype=torch.float32, device=x.device)
+    check(_lib.lib().sdmi_conv_out(ptr(x), ptr(w), ptr(bias), ptr(wpack), ptr(out), b, h, wd, cin, cout,
+                                   dtype_code(x.dtype), stream_ptr()), "conv_out")
+    return out
+
+
 def linear(x, w_packed, bias=None, resid=None, geglu=False, splits=1):
     """x: (rows, K) -> (rows, N)."""
     rows, K = x.shape

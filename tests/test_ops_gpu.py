@@ -522,3 +522,62 @@ def test_g2_resblock(ops, dt, name, cin):
         skip = x
     y = ops.conv2d(h, ops.pack_weight(sd[p + ".out_layers.3.weight"], dt), sd[p + ".out_layers.3.bias"], resid=skip)
     assert max_rel_err(nchw(y), g[name]) < TOL[dt] * 2
+
+
+# ---- boundary convolutions (NCHW fp32 <-> NHWC) -------------------------------------------------------
+IN_CASES = [   # name, B, H, W, source channels, Cout
+    ("unet", 2, 16, 16, (4,), 320),
+    ("hybrid", 1, 12, 20, (4, 1, 4), 320),          # W not a multiple of the 16-pixel groups
+    ("ragged", 3, 5, 7, (4,), 64),                  # 105 pixels: the last group is short, groups straddle samples
+    ("vae_enc", 1, 9, 9, (3,), 128),
+    ("vae_dec", 2, 8, 8, (4,), 512),
+    ("scalar_shape", 1, 6, 6, (5,), 40),            # no MFMA kernel for this Cin / Cout
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", IN_CASES, ids=[c[0] for c in IN_CASES])
+def test_conv_in(ops, dt, case, monkeypatch):
+    """First convolution on both kernels (matrix-core and scalar) against F.conv2d in fp32."""
+    name, B, H, W, cs, Co = case
+    srcs = [rnd(f"cin.{name}.x{i}", (B, c, H, W), -2, 2) for i, c in enumerate(cs)]
+    w = rnd(f"cin.{name}.w", (Co, sum(cs), 3, 3), -0.3, 0.3)
+    b = rnd(f"cin.{name}.b", (Co,))
+    ref = F.conv2d(torch.cat(srcs, 1), w, b, padding=1)
+    outs = []
+    for scalar in ("0", "1"):
+        monkeypatch.setenv("SDMI_BOUNDARY_SCALAR", scalar)
+        y = ops.conv_in([s.cuda() for s in srcs], w.cuda(), b.cuda(), dt)
+        torch.cuda.synchronize()
+        assert max_rel_err(nchw(y), ref) < TOL[dt], (name, dt, scalar)
+        outs.append(y)
+    # same products, same summation order (bias, taps, channels): the two kernels agree to the last bit
+    assert torch.equal(outs[0], outs[1])
+
+
+OUT_CASES = [  # name, B, H, W, Cin, Cout
+    ("unet", 2, 16, 16, 320, 4),
+    ("unet_ragged", 3, 5, 7, 320, 4),
+    ("vae", 1, 24, 20, 128, 3),
+    ("moments", 1, 8, 8, 128, 8),
+    ("scalar_shape", 1, 6, 10, 64, 4),
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("case", OUT_CASES, ids=[c[0] for c in OUT_CASES])
+def test_conv_out(ops, dt, case, monkeypatch):
+    """Last convolution on both kernels against F.conv2d on the same (dtype-rounded) activations; the weights
+    stay fp32 in both (the matrix-core kernel carries them as hi + lo halves)."""
+    name, B, H, W, Ci, Co = case
+    x = rnd(f"cout.{name}.x", (B, Ci, H, W), -2, 2)
+    w = rnd(f"cout.{name}.w", (Co, Ci, 3, 3), -0.05, 0.05)
+    b = rnd(f"cout.{name}.b", (Co,))
+    ref = F.conv2d(q(x, dt), w, b, padding=1)
+    for scalar in ("0", "1"):
+        monkeypatch.setenv("SDMI_BOUNDARY_SCALAR", scalar)
+        y = ops.conv_out(nhwc(x, dt), w.cuda(), b.cuda())
+        torch.cuda.synchronize()
+        assert tuple(y.shape) == (B, Co, H, W)
+        # inputs are identical, products exact in fp32 up to the 2^-22 weight split: fp32-level agreement in every mode
+        assert max_rel_err(y.cpu(), ref) < 2e-5, (name, dt, scalar)

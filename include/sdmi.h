@@ -250,6 +250,17 @@ int sdmi_groupnorm_static(const void* x0, int c0, const void* x1, int c1, int ba
 /* nn.LayerNorm (:2807-2809) over the last dim */
 int sdmi_layernorm(const void* x, void* out, const float* gamma, const float* beta, int rows, int d, float eps,
                    int dtype, void* stream);
+/* Linear(LayerNorm(x)) as ONE pass over x: the GEMM reads the raw rows, the weights carry gamma and the
+ * epilogue applies mean, rstd and W beta (y = rstd (x (W diag gamma)^T - mean colsum) + b + W beta).  Replaces
+ * the pairs norm1 -> attn1.to_q/k/v, norm2 -> attn2.to_q and norm3 -> ff.net[0].proj of BasicTransformerBlock
+ * (:2815-2819, :2780-2782, :2703).  x: [rows][k] in dtype; w: fp32 (n, k) in checkpoint layout; bias may be NULL;
+ * geglu = 1: w is the (2F, k) GEGLU projection and out is [rows][F] = value * gelu(gate); splits as in
+ * sdmi_conv2d.  workspace: sdmi_layernorm_linear_workspace_bytes(...) bytes of device memory (the UNet handle
+ * folds and packs once at load and keeps only the per-row statistics in its workspace). */
+int64_t sdmi_layernorm_linear_workspace_bytes(int rows, int k, int n, int splits, int dtype);
+int sdmi_layernorm_linear(const void* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                          float eps, void* out, int rows, int k, int n, int geglu, int splits, void* workspace,
+                          int dtype, void* stream);
 /* Pack an OIHW (or (out,in) with taps = 1) fp32 weight to the conv/linear kernel layout. */
 int sdmi_pack_weight(const float* w, void* out, int out_ch, int in_ch, int taps, int dtype, void* stream);
 int sdmi_pack_geglu(const float* w, const float* b, void* wout, float* bout, int inner, int in_ch, int dtype,

@@ -94,6 +94,9 @@ SIGNATURES = {
     "sdmi_groupnorm_static": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                       c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "sdmi_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
+    "sdmi_layernorm_linear_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "sdmi_layernorm_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int,
+                                      c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "sdmi_pack_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "sdmi_pack_geglu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "sdmi_conv2d": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

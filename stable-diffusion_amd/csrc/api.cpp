@@ -185,6 +185,54 @@ int sdmi_layernorm(const void* x, void* out, const float* gamma, const float* be
   return layernorm(x, out, gamma, beta, rows, d, eps, dtype, (hipStream_t)stream);
 }
 
+// workspace layout of sdmi_layernorm_linear: [folded fp32 W][b' (source order)][b' (packed order)][colsum][row stats]
+// [packed W][split-K slabs], every part rounded up to 256 bytes
+namespace {
+struct LnLinearWs { size_t fw, fb, pb, cs, st, pw, sk, total; };
+LnLinearWs ln_linear_ws(int rows, int k, int n, int splits, int dtype) {
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  LnLinearWs w;
+  size_t o = 0;
+  w.fw = o; o += up((size_t)n * k * 4);
+  w.fb = o; o += up((size_t)n * 4);
+  w.pb = o; o += up((size_t)n * 4);
+  w.cs = o; o += up((size_t)n * 4);
+  w.st = o; o += up((size_t)rows * 8);
+  w.pw = o; o += up((size_t)n * k * sdmi_dtype_size(dtype));
+  w.sk = o; o += up(splits > 1 ? (size_t)splits * rows * n * 4 : 0);
+  w.total = o;
+  return w;
+}
+}  // namespace
+
+int64_t sdmi_layernorm_linear_workspace_bytes(int rows, int k, int n, int splits, int dtype) {
+  return (int64_t)ln_linear_ws(rows, k, n, splits, dtype).total;
+}
+
+int sdmi_layernorm_linear(const void* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                          float eps, void* out, int rows, int k, int n, int geglu, int splits, void* workspace,
+                          int dtype, void* stream) {
+  SDMI_REQUIRE(x && w && gamma && beta && out && workspace, "layernorm_linear: null pointer");
+  SDMI_REQUIRE(!geglu || (bias && n % 32 == 0), "layernorm_linear: GEGLU needs a bias and n a multiple of 32");
+  hipStream_t s = (hipStream_t)stream;
+  const LnLinearWs ws = ln_linear_ws(rows, k, n, splits, dtype);
+  char* base = (char*)workspace;
+  float* fw = (float*)(base + ws.fw); float* fb = (float*)(base + ws.fb); float* pb = (float*)(base + ws.pb);
+  float* cs = (float*)(base + ws.cs); float* st = (float*)(base + ws.st);
+  void* pw = base + ws.pw;
+  SDMI_TRY(fold_ln_weight(w, gamma, beta, bias, fw, fb, n, k, s));
+  if (geglu) SDMI_TRY(pack_geglu_weight(fw, fb, pw, pb, n / 2, k, dtype, s));
+  else SDMI_TRY(pack_conv_weight(fw, pw, n, k, 1, dtype, s));
+  SDMI_TRY(packed_rowsum(pw, cs, n, k, dtype, s));
+  SDMI_TRY(layernorm_stats(x, st, rows, k, eps, dtype, s));
+  ConvGemmArgs a;
+  a.a0 = x; a.c0 = k; a.w = pw; a.bias = geglu ? pb : fb; a.out = out; a.ldo = geglu ? n / 2 : n;
+  a.B = 1; a.Hin = 1; a.Win = rows; a.Ho = 1; a.Wo = rows; a.taps = 1; a.N = n; a.geglu = geglu; a.dtype = dtype;
+  a.splits = splits; a.partial = splits > 1 ? (float*)(base + ws.sk) : nullptr;
+  a.ln_stats = st; a.ln_colsum = cs;
+  return conv_gemm(a, s);
+}
+
 int sdmi_pack_weight(const float* w, void* out, int out_ch, int in_ch, int taps, int dtype, void* stream) {
   return pack_conv_weight(w, out, out_ch, in_ch, taps, dtype, (hipStream_t)stream);
 }

@@ -239,6 +239,38 @@ __global__ void pack_geglu_weight_kernel(const float* w, const float* b, T* wout
   }
 }
 
+// LayerNorm folded into the Linear behind it: y = LN(x) W^T + b = rstd (x W'^T - mean c) + b' with
+// W'[n][k] = gamma[k] W[n][k], c[n] = sum_k W'[n][k] (over the values as the GEMM will see them, see
+// packed_rowsum_kernel) and b'[n] = b[n] + sum_k beta[k] W[n][k].  One wave per output row, lanes fold in a
+// fixed order.
+__global__ __launch_bounds__(256) void fold_ln_weight_kernel(const float* w, const float* gamma, const float* beta,
+                                                             const float* bias, float* w_out, float* b_out, int N,
+                                                             int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float wv = w[(size_t)n * K + k];
+    w_out[(size_t)n * K + k] = wv * gamma[k];
+    acc += beta[k] * wv;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) b_out[n] = acc + (bias ? bias[n] : 0.f);
+}
+
+// c[n] = sum_k Wp[n][k] over a packed [N][K] matrix in its stored precision
+template <typename T>
+__global__ __launch_bounds__(256) void packed_rowsum_kernel(const T* wp, float* c, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc += to_f32<T>(wp[(size_t)n * K + k]);
+  acc = wave_sum(acc);
+  if (lane == 0) c[n] = acc;
+}
+
 __global__ void pack_inconv_weight_kernel(const float* w, float* out, int O, int I) {
   const size_t total = (size_t)O * I * 9;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -476,6 +508,20 @@ int pack_conv_weight(const float* w, void* out, int O, int I, int taps, int dtyp
   return SDMI_OK;
 }
 
+int fold_ln_weight(const float* w, const float* gamma, const float* beta, const float* bias, float* w_out,
+                   float* b_out, int N, int K, hipStream_t s) {
+  SDMI_REQUIRE(w && gamma && beta && w_out && b_out && N > 0 && K > 0, "fold_ln_weight: bad arguments");
+  hipLaunchKernelGGL(fold_ln_weight_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w, gamma, beta, bias, w_out, b_out, N, K);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+int packed_rowsum(const void* wp, float* c, int N, int K, int dtype, hipStream_t s) {
+  SDMI_REQUIRE(wp && c && N > 0 && K > 0, "packed_rowsum: bad arguments");
+  SDMI_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(packed_rowsum_kernel<T>, dim3((N + 3) / 4), dim3(256), 0, s,
+                                                   (const T*)wp, c, N, K));
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
 int pack_geglu_weight(const float* w, const float* b, void* wout, float* bout, int F, int I, int dtype,
                       hipStream_t s) {
   SDMI_REQUIRE(w && b && wout && bout && F % 16 == 0, "pack_geglu_weight: bad arguments");

@@ -59,6 +59,8 @@ struct GemmParams {
   const char* zero;   // 256 zero bytes (halo / out-of-range rows read these)
   int dup_rows;       // > 0: rows are stored a second time dup_rows further down
   int wide_store;     // large-tile kernel: 16-bit output written through the LDS strips
+  const float* ln_stats;   // LayerNorm folded in: per row (rstd, rstd * mean); null = plain GEMM
+  const float* ln_colsum;  // ... and per column sum_k w[n][k]; `bias` is then b' and is applied after the scaling
 };
 
 template <typename T> struct Frag;      // 16 bytes of T as an MFMA operand fragment
@@ -127,6 +129,28 @@ __device__ __forceinline__ void epilogue_store_geglu(const GemmParams& p, int m,
   typedef T Tx4 __attribute__((ext_vector_type(4)));
   Tx4 ov = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
   *reinterpret_cast<Tx4*>(o) = ov;
+}
+
+// LayerNorm folded into the GEMM: the operand rows were the raw x and the weights carry gamma, so the sums
+// S_mn become rstd_m * (S_mn - mean_m * colsum_n) + b'_n.  Applied to the accumulators in registers ahead of
+// the epilogue proper; acc[i][j] holds columns n_lane + 16 i .. +3 of row m_lane + 16 j.
+template <int NI, int MJ>
+__device__ __forceinline__ void ln_fold_acc(const GemmParams& p, f32x4 (&acc)[NI][MJ], int m_lane, int n_lane) {
+  float r[MJ], rm[MJ];
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+    const float2 st = reinterpret_cast<const float2*>(p.ln_stats)[min(m_lane + 16 * j, p.M - 1)];
+    r[j] = st.x; rm[j] = st.y;
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int n = min(n_lane + 16 * i, p.N - 4);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) b = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) acc[i][j] = r[j] * acc[i][j] + (b - rm[j] * c);
+  }
 }
 
 // Epilogue of one wave: acc[i][j] holds columns n_wave + 16 i + 4 fq .. +3 of row m_lane + 16 j.
@@ -420,6 +444,13 @@ __global__ __launch_bounds__(S::NTHREADS) void conv_gemm_kernel(GemmParams p) {
   }
 
   // ---- epilogue -----------------------------------------------------------------------------
+  if (p.ln_stats && !p.partial) {
+    ln_fold_acc<4, 4>(p, acc, m0 + wm * 64 + frow, n0 + wn * 64 + fq * 4);
+    GemmParams pe = p;
+    pe.bias = nullptr;                       // b' went in with the fold
+    store_wave_tile<T, 4, 4>(pe, acc, m0 + wm * 64 + frow, n0 + wn * 64, fq);
+    return;
+  }
   store_wave_tile<T, 4, 4>(p, acc, m0 + wm * 64 + frow, n0 + wn * 64, fq);
 }
 
@@ -655,23 +686,48 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   // is left with the residual only.
   f32x4 acc[NFW][MJ];
   const bool own_epilogue = p.partial == nullptr;
+  // LayerNorm folded in (and this launch owns the epilogue): y = rstd (S - mean c) + b'.  The accumulators start
+  // from b'_n / rstd_m - mean_m c_n, so that all that is left for the epilogue is the row scaling by rstd_m.
+  const bool ln_mode = own_epilogue && p.ln_stats != nullptr;
+  float ln_r[MJ];
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) ln_r[j] = 1.f;
   {
     const int ncol = n0 + grp * (S::BN / 2) + fq * 4;
-#pragma unroll
-    for (int i = 0; i < NFW; ++i) {
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-      if (own_epilogue && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + ncol + i * 16);
-#pragma unroll
-      for (int j = 0; j < MJ; ++j) acc[i][j] = bv;
-    }
-    if (own_epilogue && p.rowadd) {
+    if (ln_mode) {
+      float inv[MJ], mean[MJ];
 #pragma unroll
       for (int j = 0; j < MJ; ++j) {
-        const int m = min(m0 + wr * WROWS + j * 16 + frow, p.M - 1);
-        const float* ra = p.rowadd + (size_t)(m / hw) * p.ldra + ncol;
+        const float2 st = reinterpret_cast<const float2*>(p.ln_stats)[min(m0 + wr * WROWS + j * 16 + frow, p.M - 1)];
+        ln_r[j] = st.x;
+        inv[j] = 1.0f / st.x;
+        mean[j] = st.y * inv[j];
+      }
 #pragma unroll
-        for (int i = 0; i < NFW; ++i) acc[i][j] += *reinterpret_cast<const f32x4*>(ra + i * 16);
-        __builtin_amdgcn_sched_barrier(0);        // one row group's loads in flight at a time (registers)
+      for (int i = 0; i < NFW; ++i) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(p.ln_colsum + ncol + i * 16);
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) b = *reinterpret_cast<const f32x4*>(p.bias + ncol + i * 16);
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) acc[i][j] = b * inv[j] - mean[j] * c;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NFW; ++i) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (own_epilogue && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + ncol + i * 16);
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) acc[i][j] = bv;
+      }
+      if (own_epilogue && p.rowadd) {
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+          const int m = min(m0 + wr * WROWS + j * 16 + frow, p.M - 1);
+          const float* ra = p.rowadd + (size_t)(m / hw) * p.ldra + ncol;
+#pragma unroll
+          for (int i = 0; i < NFW; ++i) acc[i][j] += *reinterpret_cast<const f32x4*>(ra + i * 16);
+          __builtin_amdgcn_sched_barrier(0);        // one row group's loads in flight at a time (registers)
+        }
       }
     }
   }
@@ -741,6 +797,13 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   GemmParams pe = p;
   if (own_epilogue) { pe.bias = nullptr; pe.rowadd = nullptr; }      // already in the accumulators
   const int m_wave = m0 + wr * WROWS, n_wave = n0 + grp * (S::BN / 2);
+  if (ln_mode) {
+    // rstd is fetched again rather than kept in registers across the K loop
+#pragma unroll
+    for (int i = 0; i < NFW; ++i)
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) acc[i][j] *= ln_r[j];
+  }
   if (p.wide_store) {
     // all stage reads and DMAs are retired behind the last barrier: the stages are free
     float* strip = reinterpret_cast<float*>(smem + wid * (16 * (16 * NFW + 4) * 4));
@@ -782,11 +845,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
         val += *reinterpret_cast<const f32x4*>(s);
         gate += *reinterpret_cast<const f32x4*>(s + 16);
       }
+      if (p.ln_stats) {
+        const float2 st = reinterpret_cast<const float2*>(p.ln_stats)[m];
+        val = st.x * val + (*reinterpret_cast<const f32x4*>(p.bias + n) - st.y * *reinterpret_cast<const f32x4*>(p.ln_colsum + n));
+        gate = st.x * gate + (*reinterpret_cast<const f32x4*>(p.bias + n + 16) -
+                              st.y * *reinterpret_cast<const f32x4*>(p.ln_colsum + n + 16));
+        GemmParams pe = p;
+        pe.bias = nullptr;
+        epilogue_store_geglu<T>(pe, m, n, n + 16, (n >> 5) * 16 + (n & 15), val, gate);
+        continue;
+      }
       epilogue_store_geglu<T>(p, m, n, n + 16, (n >> 5) * 16 + (n & 15), val, gate);
     } else {
       f32x4 v = {0, 0, 0, 0};
       for (int z = 0; z < splits; ++z)
         v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)z * p.M + m) * p.N + n);
+      if (p.ln_stats) {
+        const float2 st = reinterpret_cast<const float2*>(p.ln_stats)[m];
+        f32x4 b = {0, 0, 0, 0};
+        if (p.bias) b = *reinterpret_cast<const f32x4*>(p.bias + n);
+        v = st.x * v + (b - st.y * *reinterpret_cast<const f32x4*>(p.ln_colsum + n));
+        GemmParams pe = p;
+        pe.bias = nullptr;
+        epilogue_store<T>(pe, m, n, v);
+        continue;
+      }
       epilogue_store<T>(p, m, n, v);
     }
   }
@@ -964,6 +1047,10 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   p.taps = a.taps; p.stride = a.stride; p.up = a.up; p.pad = a.taps == 9 ? a.pad_lo : 0;
   p.M = a.B * a.Ho * a.Wo; p.N = a.N; p.K = a.taps * (p.c0 + p.c1); p.geglu = a.geglu;
   p.dup_rows = a.dup_rows;
+  p.ln_stats = a.ln_stats; p.ln_colsum = a.ln_stats ? a.ln_colsum : nullptr;
+  SDMI_REQUIRE(!a.ln_stats || (a.ln_colsum && a.taps == 1 && !a.a1 && !a.rowadd && (!a.geglu || a.bias)),
+               "conv_gemm: a folded LayerNorm needs ln_colsum, a single-source pointwise problem without rowadd "
+               "(and a bias with GEGLU)");
   SDMI_REQUIRE(a.dup_rows == 0 || (a.dup_rows >= p.M && !a.geglu && !a.out_f32),
                "conv_gemm: dup_rows must skip past the computed rows and excludes GEGLU / fp32 outputs");
   SDMI_REQUIRE(a.a0 && a.w && a.out, "conv_gemm: null pointer");

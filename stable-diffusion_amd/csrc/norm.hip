@@ -339,6 +339,67 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, T* out, cons
   }
 }
 
+// Row statistics only: (rstd, rstd * mean) per row.  LPR lanes share a row (lane q takes the 16-byte vectors
+// q, q + LPR, ... of it, so a load instruction covers LPR * 16 contiguous bytes of each of its rows) and a wave
+// works on 64 / LPR rows at once: with 8 lanes per row the cross-lane fold is three steps for eight rows
+// instead of six per row.  Sums are taken about the row's first element (shifted data), which keeps
+// E[t^2] - E[t]^2 free of cancellation for rows with a large common offset; nothing but the two running sums
+// stays in registers.
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void layernorm_stats_kernel(const T* x, float2* stats, int rows, int d, float eps) {
+  constexpr int EPV = VecOf<T>::N, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, r = lane / LPR, q = lane % LPR;
+  const int row = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + r;
+  const T* xr = x + (size_t)min(row, rows - 1) * d;
+  const int nvec = d / EPV;
+  const float shift = to_f32<T>(xr[0]);
+  float s = 0.f, ss = 0.f;
+  int v = q;
+  for (; v + 3 * LPR < nvec; v += 4 * LPR) {          // four independent 16-byte loads in flight per lane
+    float f[4][EPV];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_vec<T>(xr + (v + LPR * u) * EPV, f[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { const float t = f[u][e] - shift; s += t; ss = fmaf(t, t, ss); }
+  }
+  for (; v < nvec; v += LPR) {
+    float f[EPV];
+    load_vec<T>(xr + v * EPV, f);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { const float t = f[e] - shift; s += t; ss = fmaf(t, t, ss); }
+  }
+#pragma unroll
+  for (int o = 1; o < LPR; o <<= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+  const float m1 = s / (float)d;
+  const float var = fmaxf(ss / (float)d - m1 * m1, 0.f);
+  const float rstd = rsqrtf(var + eps);
+  if (q == 0 && row < rows) stats[row] = make_float2(rstd, rstd * (shift + m1));
+}
+
+template <typename T>
+int launch_ln_stats(const void* x, float* stats, int rows, int d, float eps, hipStream_t stream) {
+  constexpr int EPV = VecOf<T>::N;
+  SDMI_REQUIRE(x && stats, "layernorm_stats: null pointer");
+  SDMI_REQUIRE(d % EPV == 0 && d > 0 && rows > 0, "layernorm_stats: d=%d must be a positive multiple of %d", d, EPV);
+  char label[32];
+  snprintf(label, sizeof(label), "stats rows%d d%d", rows, d);
+  ProfScope prof(PROF_LAYERNORM, stream, 0.0, (double)rows * d * sizeof(T), label);
+  float2* st = reinterpret_cast<float2*>(stats);
+  // lanes per row: as few as still give the chip about 4096 waves (16 per CU), and no more than the row has vectors
+  int lpr = 8;
+  while (lpr < 64 && (long)rows * lpr / 64 < 4096 && 2 * lpr <= d / EPV) lpr *= 2;
+  const int rpb = 4 * (64 / lpr);           // rows per 256-thread workgroup
+  const dim3 grid((rows + rpb - 1) / rpb), block(256);
+  if (lpr == 8) hipLaunchKernelGGL((layernorm_stats_kernel<T, 8>), grid, block, 0, stream, (const T*)x, st, rows, d, eps);
+  else if (lpr == 16) hipLaunchKernelGGL((layernorm_stats_kernel<T, 16>), grid, block, 0, stream, (const T*)x, st, rows, d, eps);
+  else if (lpr == 32) hipLaunchKernelGGL((layernorm_stats_kernel<T, 32>), grid, block, 0, stream, (const T*)x, st, rows, d, eps);
+  else hipLaunchKernelGGL((layernorm_stats_kernel<T, 64>), grid, block, 0, stream, (const T*)x, st, rows, d, eps);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
 template <typename T>
 int launch_ln(const void* x, void* out, const float* gamma, const float* beta, int rows, int d,
               float eps, hipStream_t stream) {
@@ -425,6 +486,11 @@ size_t groupnorm_scratch_floats(int B, int HW, int groups) {
 
 int groupnorm(const GroupNormArgs& a, hipStream_t stream) {
   SDMI_DISPATCH_DTYPE(a.dtype, T, return launch_gn<T>(a, stream));
+  return SDMI_OK;
+}
+
+int layernorm_stats(const void* x, float* stats, int rows, int d, float eps, int dtype, hipStream_t stream) {
+  SDMI_DISPATCH_DTYPE(dtype, T, return launch_ln_stats<T>(x, stats, rows, d, eps, stream));
   return SDMI_OK;
 }
 

@@ -45,6 +45,11 @@ struct ConvGemmArgs {
   // conv_gemm() launches the reduction+epilogue kernel itself.
   int splits = 1;
   float* partial = nullptr;
+  // LayerNorm folded into this GEMM (token GEMMs only): the operand rows are the raw x, `w` carries gamma, `bias`
+  // is b' = b + W beta, ln_colsum[n] = sum_k w[n][k] and ln_stats[m] = (rstd_m, rstd_m * mean_m) from
+  // layernorm_stats(); the sums become rstd_m * (S_mn - mean_m * colsum_n) + b'_n ahead of the rest of the epilogue
+  const float* ln_stats = nullptr;
+  const float* ln_colsum = nullptr;
   // > 0: every output row m is also stored at row m + dup_rows of `out` (two samples that are known to
   // be identical so far are computed once); not with GEGLU or fp32 outputs
   int dup_rows = 0;
@@ -76,6 +81,9 @@ int groupnorm_static(const GroupNormArgs& a, hipStream_t stream);
 
 int layernorm(const void* x, void* out, const float* gamma, const float* beta, int rows, int d,
               float eps, int dtype, hipStream_t stream);
+
+// per-row (rstd, rstd * mean) of nn.LayerNorm, for GEMMs that apply the normalisation in their epilogue
+int layernorm_stats(const void* x, float* stats, int rows, int d, float eps, int dtype, hipStream_t stream);
 
 // ---- attention -------------------------------------------------------------------------------
 struct AttentionArgs {
@@ -154,6 +162,11 @@ int pack_conv_weight(const float* w, void* out, int O, int I, int taps, int dtyp
 // rows of a (2F, I) fp32 matrix -> (value,gate)-interleaved 16-row groups; same permutation on bias
 int pack_geglu_weight(const float* w, const float* b, void* wout, float* bout, int F, int I, int dtype,
                       hipStream_t s);
+// LayerNorm -> Linear folding, run once at load: w_out = w diag(gamma) (fp32 [N][K]), b_out = bias + w beta;
+// packed_rowsum: c[n] = sum_k wp[n][k] of a packed matrix in its stored precision
+int fold_ln_weight(const float* w, const float* gamma, const float* beta, const float* bias, float* w_out,
+                   float* b_out, int N, int K, hipStream_t s);
+int packed_rowsum(const void* wp, float* c, int N, int K, int dtype, hipStream_t s);
 // OIHW fp32 -> [tap][I][O] fp32 for in_conv
 int pack_inconv_weight(const float* w, float* out, int O, int I, hipStream_t s);
 // OIHW fp32 -> [O][tap][I] fp32 for out_conv

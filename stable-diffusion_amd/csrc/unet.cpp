@@ -14,7 +14,10 @@
 //   * all 22 per-ResBlock time-embedding projections (:3217) are one batched tiny-M launch;
 //   * context K/V (:2781-2782) are projected once per prompt (set_context) for all 16 blocks.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
 
 #include <memory>
 
@@ -37,6 +40,9 @@ struct TBlockW {
   const float *ln_g[3] = {nullptr, nullptr, nullptr}, *ln_b[3] = {nullptr, nullptr, nullptr};
   PackedConv qkv, out1, q2, kv2, out2, ff1, ff2;
   float* ff1_bias = nullptr;       // permuted to the GEGLU row order
+  // LayerNorm folded into qkv / q2 / ff1 (16-bit modes): per output column sum_k of the packed weights (which then
+  // carry gamma); the PackedConv's bias is b' = b + W beta
+  float *qkv_c = nullptr, *q2_c = nullptr, *ff1_c = nullptr;
   void* kv_cache = nullptr;        // [B*ntok][2*inner]
 };
 
@@ -100,6 +106,11 @@ struct sdmi_unet {
   // cross-attention is computed for one half and stored twice
   int cfg_dup = 0;
   int next_dup_rows = 0;        // consumed by the next gemm()
+  // LayerNorm folded into the Linear behind it (decided at finalize: 16-bit compute types; SDMI_LN_FOLD=0 keeps
+  // the separate kernel); next_ln_* are consumed by the next gemm()
+  bool fold_ln = false;
+  const float* next_ln_stats = nullptr;
+  const float* next_ln_colsum = nullptr;
 
   // graph replay
   int graph_mode = 1;
@@ -276,6 +287,32 @@ struct sdmi_unet {
     SDMI_TRY(elementwise_init());
     SDMI_TRY(attention_init());
     std::vector<std::string> packed_keys;
+    {
+      const char* e = getenv("SDMI_LN_FOLD");
+      fold_ln = dtype != SDMI_F32 && !(e && atoi(e) == 0);
+    }
+    // scratch for one folded fp32 matrix (the widest is the GEGLU projection, 8d x d) and its bias
+    float *fold_w = nullptr, *fold_b = nullptr;
+    if (fold_ln) {
+      size_t widest = 0;
+      for (auto& st : sts) widest = std::max(widest, (size_t)8 * st.inner * st.inner);
+      void* q;
+      SDMI_TRY(mem.alloc(&q, widest * 4)); fold_w = (float*)q;
+      SDMI_TRY(mem.alloc(&q, (size_t)8 * 4096 * 4)); fold_b = (float*)q;
+    }
+    // W diag(gamma) packed into `dst` rows [row0, row0 + rows), b' = W beta (+ bias) into bprime[row0 ...]
+    auto fold_into = [&](void* dst, float* bprime, int row0, const std::string& wkey, const std::string& bkey,
+                         const float* g, const float* b, int rows, int cin) -> int {
+      SDMI_TRY(fold_ln_weight(store.get(wkey), g, b, bkey.empty() ? nullptr : store.get(bkey), fold_w, bprime + row0,
+                              rows, cin, s));
+      return pack_conv_weight(fold_w, (char*)dst + (size_t)row0 * cin * sdmi_dtype_size(dtype), rows, cin, 1, dtype, s);
+    };
+    auto alloc_f = [&](float** out, size_t n) -> int {
+      void* q;
+      SDMI_TRY(mem.alloc(&q, n * 4));
+      *out = (float*)q;
+      return SDMI_OK;
+    };
     auto P = [&](PackedConv* pc, const std::string& prefix, int cout, int cin, int taps, bool bias = true) {
       packed_keys.push_back(prefix + ".weight");
       return pack(pc, prefix + ".weight", bias ? prefix + ".bias" : std::string(), cout, cin, taps, s);
@@ -326,22 +363,50 @@ struct sdmi_unet {
           tb.ln_b[n] = store.get(q + ".norm" + std::to_string(n + 1) + ".bias");
         }
         std::vector<std::string> qkv = {q + ".attn1.to_q.weight", q + ".attn1.to_k.weight", q + ".attn1.to_v.weight"};
-        SDMI_TRY(pack_stacked(&tb.qkv, qkv, d, d, s));
         std::vector<std::string> kv = {q + ".attn2.to_k.weight", q + ".attn2.to_v.weight"};
         SDMI_TRY(pack_stacked(&tb.kv2, kv, d, cfg.context_dim, s));
-        packed_keys.insert(packed_keys.end(), qkv.begin(), qkv.end());
-        packed_keys.insert(packed_keys.end(), kv.begin(), kv.end());
         SDMI_TRY(P(&tb.out1, q + ".attn1.to_out.0", d, d, 1));
-        SDMI_TRY(P(&tb.q2, q + ".attn2.to_q", d, d, 1, false));
         SDMI_TRY(P(&tb.out2, q + ".attn2.to_out.0", d, d, 1));
         SDMI_TRY(P(&tb.ff2, q + ".ff.net.2", d, 4 * d, 1));
         tb.ff1.cin = d; tb.ff1.cout = 8 * d; tb.ff1.taps = 1;
         SDMI_TRY(mem.alloc(&tb.ff1.w, (size_t)8 * d * d * sdmi_dtype_size(dtype)));
-        void* bp;
-        SDMI_TRY(mem.alloc(&bp, (size_t)8 * d * 4));
-        tb.ff1_bias = (float*)bp;
-        SDMI_TRY(pack_geglu_weight(store.get(q + ".ff.net.0.proj.weight"), store.get(q + ".ff.net.0.proj.bias"),
-                                   tb.ff1.w, tb.ff1_bias, 4 * d, d, dtype, s));
+        SDMI_TRY(alloc_f(&tb.ff1_bias, (size_t)8 * d));
+        const size_t esz_w = sdmi_dtype_size(dtype);
+        if (fold_ln) {
+          SDMI_REQUIRE(8 * d <= 8 * 4096, "%s: inner dimension %d too wide for the LayerNorm fold", q.c_str(), d);
+          // norm1 -> fused q/k/v projection
+          tb.qkv.cin = d; tb.qkv.cout = 3 * d; tb.qkv.taps = 1;
+          SDMI_TRY(mem.alloc(&tb.qkv.w, (size_t)3 * d * d * esz_w));
+          float* b;
+          SDMI_TRY(alloc_f(&b, (size_t)3 * d));
+          for (int i = 0; i < 3; ++i)
+            SDMI_TRY(fold_into(tb.qkv.w, b, i * d, qkv[i], "", tb.ln_g[0], tb.ln_b[0], d, d));
+          tb.qkv.bias = b;
+          SDMI_TRY(alloc_f(&tb.qkv_c, (size_t)3 * d));
+          SDMI_TRY(packed_rowsum(tb.qkv.w, tb.qkv_c, 3 * d, d, dtype, s));
+          // norm2 -> cross-attention query projection
+          tb.q2.cin = d; tb.q2.cout = d; tb.q2.taps = 1;
+          SDMI_TRY(mem.alloc(&tb.q2.w, (size_t)d * d * esz_w));
+          SDMI_TRY(alloc_f(&b, (size_t)d));
+          SDMI_TRY(fold_into(tb.q2.w, b, 0, q + ".attn2.to_q.weight", "", tb.ln_g[1], tb.ln_b[1], d, d));
+          tb.q2.bias = b;
+          SDMI_TRY(alloc_f(&tb.q2_c, (size_t)d));
+          SDMI_TRY(packed_rowsum(tb.q2.w, tb.q2_c, d, d, dtype, s));
+          // norm3 -> GEGLU projection: fold in checkpoint row order, then the (value, gate) interleave
+          SDMI_TRY(fold_ln_weight(store.get(q + ".ff.net.0.proj.weight"), tb.ln_g[2], tb.ln_b[2],
+                                  store.get(q + ".ff.net.0.proj.bias"), fold_w, fold_b, 8 * d, d, s));
+          SDMI_TRY(pack_geglu_weight(fold_w, fold_b, tb.ff1.w, tb.ff1_bias, 4 * d, d, dtype, s));
+          SDMI_TRY(alloc_f(&tb.ff1_c, (size_t)8 * d));
+          SDMI_TRY(packed_rowsum(tb.ff1.w, tb.ff1_c, 8 * d, d, dtype, s));
+          packed_keys.push_back(q + ".attn2.to_q.weight");
+        } else {
+          SDMI_TRY(pack_stacked(&tb.qkv, qkv, d, d, s));
+          SDMI_TRY(P(&tb.q2, q + ".attn2.to_q", d, d, 1, false));
+          SDMI_TRY(pack_geglu_weight(store.get(q + ".ff.net.0.proj.weight"), store.get(q + ".ff.net.0.proj.bias"),
+                                     tb.ff1.w, tb.ff1_bias, 4 * d, d, dtype, s));
+        }
+        packed_keys.insert(packed_keys.end(), qkv.begin(), qkv.end());
+        packed_keys.insert(packed_keys.end(), kv.begin(), kv.end());
         tb.ff1.bias = tb.ff1_bias;
         packed_keys.push_back(q + ".ff.net.0.proj.weight");
         packed_keys.push_back(q + ".ff.net.0.proj.bias");
@@ -351,6 +416,8 @@ struct sdmi_unet {
     for (auto& c : ups) SDMI_TRY(P(&c.conv, c.prefix, c.ch, c.ch, 9));
     SDMI_CHECK_HIP(hipStreamSynchronize(s));
     for (const auto& k : packed_keys) store.drop(k);
+    if (fold_w) mem.release(fold_w);
+    if (fold_b) mem.release(fold_b);
     finalized = true;
     return SDMI_OK;
   }
@@ -404,6 +471,8 @@ struct sdmi_unet {
     g.B = B; g.Hin = Hin; g.Win = Win; g.Ho = Ho; g.Wo = Wo; g.taps = pc.taps; g.stride = stride; g.up = up;
     g.N = pc.cout; g.geglu = geglu; g.dtype = dtype;
     g.dup_rows = next_dup_rows; next_dup_rows = 0;
+    g.ln_stats = next_ln_stats; g.ln_colsum = next_ln_colsum;
+    next_ln_stats = next_ln_colsum = nullptr;
     const int M = B * Ho * Wo, K = pc.taps * (c0 + (a1 ? c1 : 0));
     g.splits = conv_gemm_pick_splits(M, pc.cout, K, dtype, geglu != 0);
     if (g.splits > 1) g.partial = (float*)ws.get("splitk", (size_t)g.splits * M * pc.cout * 4);
@@ -484,35 +553,47 @@ struct sdmi_unet {
     SDMI_REQUIRE(x.C == st.ch, "%s: got %d channels, expected %d", st.prefix.c_str(), x.C, st.ch);
     void* nrm = ws.get("nrm", act_bytes(B, H, W, st.ch));
     void* xt = ws.get("xt", (size_t)rows * d * esz);
-    void* lnb = ws.get("ln", (size_t)rows * d * esz);
+    void* lnb = fold_ln ? nullptr : ws.get("ln", (size_t)rows * d * esz);
+    float* lnst = fold_ln ? (float*)ws.get("lnstat", (size_t)rows * 2 * 4) : nullptr;
     void* qkv = ws.get("qkv", (size_t)rows * 3 * d * esz);
     void* att = ws.get("att", (size_t)rows * d * esz);
     void* ffm = ws.get("ffm", (size_t)rows * 4 * d * esz);
     y->p = ws.get(out_role, act_bytes(B, H, W, st.ch)); y->H = H; y->W = W; y->C = st.ch;
     SDMI_TRY(gn(x, nullptr, Bh, st.gn_g, st.gn_b, 1e-6f, 0, nrm, f.s));
     SDMI_TRY(linear(nrm, st.ch, st.proj_in, xt, d, rows_h, nullptr, 0, 0, f.s));
+    // Linear(LayerNorm(xt)): either the normalised copy goes through HBM (fp32 mode), or only the row statistics
+    // do and the GEMM reads xt itself (weights carry gamma, the epilogue applies mean, rstd and W beta)
+    auto ln_linear = [&](const TBlockW& tb, int which, const float* colsum, const PackedConv& pc, void* out, int ldo,
+                         int nrows, int geglu, int dup_rows) -> int {
+      const void* a = xt;
+      if (fold_ln) {
+        if (!ws.dry) SDMI_TRY(layernorm_stats(xt, lnst, nrows, d, 1e-5f, dtype, f.s));
+        next_ln_stats = lnst; next_ln_colsum = colsum;
+      } else {
+        SDMI_TRY(ln(xt, lnb, tb.ln_g[which], tb.ln_b[which], nrows, d, f.s));
+        a = lnb;
+      }
+      next_dup_rows = dup_rows;
+      return linear(a, d, pc, out, ldo, nrows, nullptr, 0, geglu, f.s);
+    };
     bool first = true;
     for (const auto& tb : st.blocks) {
       const bool half = dup && first;             // later blocks see diverged halves
       const int bq = half ? Bh : B, rq = half ? rows_h : rows;
       first = false;
       // self-attention
-      SDMI_TRY(ln(xt, lnb, tb.ln_g[0], tb.ln_b[0], rq, d, f.s));
-      SDMI_TRY(linear(lnb, d, tb.qkv, qkv, 3 * d, rq, nullptr, 0, 0, f.s));
+      SDMI_TRY(ln_linear(tb, 0, tb.qkv_c, tb.qkv, qkv, 3 * d, rq, 0, 0));
       SDMI_TRY(attn(qkv, 3 * d, (char*)qkv + (size_t)d * esz, 3 * d, (char*)qkv + (size_t)2 * d * esz, 3 * d, att, d,
                     bq, st.heads, N, N, st.dh, f.s));
       if (half) next_dup_rows = rows_h;
       SDMI_TRY(linear(att, d, tb.out1, xt, d, rq, xt, d, 0, f.s));
       // cross-attention against the cached context projections
-      SDMI_TRY(ln(xt, lnb, tb.ln_g[1], tb.ln_b[1], rq, d, f.s));
-      if (half) next_dup_rows = rows_h;
-      SDMI_TRY(linear(lnb, d, tb.q2, qkv, d, rq, nullptr, 0, 0, f.s));
+      SDMI_TRY(ln_linear(tb, 1, tb.q2_c, tb.q2, qkv, d, rq, 0, half ? rows_h : 0));
       SDMI_TRY(attn(qkv, d, tb.kv_cache, 2 * d, (char*)tb.kv_cache + (size_t)d * esz, 2 * d, att, d, B, st.heads, N,
                     ctx_ntok, st.dh, f.s));
       SDMI_TRY(linear(att, d, tb.out2, xt, d, rows, xt, d, 0, f.s));
       // GEGLU feed-forward
-      SDMI_TRY(ln(xt, lnb, tb.ln_g[2], tb.ln_b[2], rows, d, f.s));
-      SDMI_TRY(linear(lnb, d, tb.ff1, ffm, 4 * d, rows, nullptr, 0, 1, f.s));
+      SDMI_TRY(ln_linear(tb, 2, tb.ff1_c, tb.ff1, ffm, 4 * d, rows, 1, 0));
       SDMI_TRY(linear(ffm, 4 * d, tb.ff2, xt, d, rows, xt, d, 0, f.s));
     }
     SDMI_TRY(linear(xt, d, st.proj_out, y->p, st.ch, rows, x.p, st.ch, 0, f.s));

@@ -136,6 +136,24 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return out
 
 
+def layernorm_linear(x, w, bias, gamma, beta, eps=1e-5, geglu=False, splits=1):
+    """Linear(LayerNorm(x)) with the normalisation folded into the GEMM.  x: (rows, K) in the compute dtype; w:
+    fp32 (N, K) as in the checkpoint; returns (rows, N), or (rows, N/2) = value * gelu(gate) with ``geglu``."""
+    x = x.contiguous()
+    rows, K = x.shape
+    w = _f32(w.contiguous())
+    N = w.shape[0]
+    if splits is None:
+        splits = _lib.lib().sdmi_conv2d_splits(rows, N, K, dtype_code(x.dtype))
+    out = torch.empty((rows, N // 2 if geglu else N), dtype=x.dtype, device=x.device)
+    nbytes = _lib.lib().sdmi_layernorm_linear_workspace_bytes(rows, K, N, splits, dtype_code(x.dtype))
+    wsp = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    check(_lib.lib().sdmi_layernorm_linear(ptr(x), ptr(w), ptr(bias), ptr(_f32(gamma)), ptr(_f32(beta)), eps, ptr(out),
+                                           rows, K, N, 1 if geglu else 0, splits, ptr(wsp), dtype_code(x.dtype),
+                                           stream_ptr()), "layernorm_linear")
+    return out
+
+
 def attention(q, k, v, heads, scale=None, impl=0, causal=False):
     """q: (B,Nq,heads*d), k/v: (B,Nk,heads*d) (may be strided views over the last dim) -> (B,Nq,heads*d)."""
     impl = (impl & 1) | (2 if causal else 0)

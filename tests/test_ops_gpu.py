@@ -581,3 +581,49 @@ def test_conv_out(ops, dt, case, monkeypatch):
         assert tuple(y.shape) == (B, Co, H, W)
         # inputs are identical, products exact in fp32 up to the 2^-22 weight split: fp32-level agreement in every mode
         assert max_rel_err(y.cpu(), ref) < 2e-5, (name, dt, scalar)
+
+
+# ---- LayerNorm folded into the Linear behind it --------------------------------------------------------
+LNL_CASES = [   # name, rows, K, N, geglu, splits, bias
+    ("qkv_small", 128, 320, 960, False, 1, False),           # 128x128 kernel
+    ("q_small_edge", 200, 320, 320, False, 1, False),        # row tail inside a tile
+    ("ff1_small", 128, 320, 2560, True, 1, True),
+    ("qkv_large", 4096, 320, 960, False, 1, False),          # large-tile kernels
+    ("ff1_large", 2048, 640, 5120, True, 1, True),
+    ("q_d1280", 1024, 1280, 1280, False, None, False),       # the executor's own split choice
+    ("splitk", 256, 1280, 1280, False, 4, True),             # slabs + reduction pass apply the fold
+    ("ff1_splitk", 128, 1280, 10240, True, 2, True),
+]
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16", "fp32"])
+@pytest.mark.parametrize("case", LNL_CASES, ids=[c[0] for c in LNL_CASES])
+def test_layernorm_linear(ops, dt, case):
+    """Linear(LayerNorm(x)) as one pass: against torch fp32 on the same (dtype-rounded) x.  The rows carry a common
+    offset several times their spread, the case in which folding the mean into the epilogue cancels the most."""
+    name, rows, K, N, geglu, splits, with_bias = case
+    x = q(rnd(f"lnl.{name}.x", (rows, K), -1.5, 1.5) + rnd(f"lnl.{name}.off", (rows, 1), -4.0, 4.0), dt)
+    w = rnd(f"lnl.{name}.w", (N, K), -0.05, 0.05)
+    b = rnd(f"lnl.{name}.b", (N,)) if with_bias else None
+    gamma, beta = rnd(f"lnl.{name}.g", (K,), 0.5, 1.5), rnd(f"lnl.{name}.be", (K,), -0.5, 0.5)
+    ref = F.linear(F.layer_norm(x, (K,), gamma, beta, 1e-5), w, b)
+    if geglu:
+        a, gate = ref.chunk(2, dim=-1)
+        ref = a * F.gelu(gate)
+    y = ops.layernorm_linear(x.cuda().to(tdt(dt)), w.cuda(), None if b is None else b.cuda(), gamma.cuda(),
+                             beta.cuda(), geglu=geglu, splits=splits)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == tuple(ref.shape)
+    err = max_rel_err(y.float().cpu(), ref)
+    # two-stage reference: the unfused device path (LayerNorm kernel, then the plain GEMM) for comparison
+    ln = ops.layernorm(x.cuda().to(tdt(dt)), gamma.cuda(), beta.cuda())
+    if geglu:
+        wp, bp = ops.pack_geglu(w.cuda(), b.cuda(), dt)
+        y2 = ops.linear(ln, wp, bp, geglu=True)
+    else:
+        y2 = ops.linear(ln, ops.pack_weight(w.cuda(), dt), None if b is None else b.cuda())
+    err2 = max_rel_err(y2.float().cpu(), ref)
+    print(f"layernorm_linear {name} {dt}: folded {err:.3e}, two-stage {err2:.3e}")
+    assert err < TOL[dt] * (2 if geglu else 1), (name, dt, err)
+    if dt != "fp32":      # the executor folds in the 16-bit modes only; there it must not cost accuracy
+        assert err < 2 * err2 + 1e-6, "the fold must not be less accurate than LayerNorm -> GEMM"

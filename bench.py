@@ -103,13 +103,16 @@ def prof_dump_by_label(lib):
 
 
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (None if absent)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        return None
+    """(HBM bytes per launch of the dominant kernel, file it came from) from the newest committed rocprofv3 --pmc
+    summary (tools/profile_round.sh: counters need passes of their own, so this run cannot measure them)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                return json.load(f).get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
 def cpu_baseline(ddim_steps, size, with_clip=True):
@@ -342,7 +345,8 @@ def main():
         achieved = dom_fl / (dom_us * 1e-6) / 1e12 if dom else 0.0
         result["roofline"] = {
             "bound": "mfma", "kernel": DOMINANT_NAME.format(elem={"fp16": "half", "bf16": "bfloat16"}.get(args.dtype, "float")),
-            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic(),
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic()[0],
+            "traffic_source": pmc_traffic()[1],
             "launches": len(dom), "avg_launch_us": dom_us / max(1, len(dom)),
             "flops_per_launch": dom_fl / max(1, len(dom)), "kernel_ms_per_step": dom_us * 1e-3,
             "algorithmic_bytes_per_launch": sum(r[4] for r in dom) / max(1, len(dom)),

@@ -21,6 +21,7 @@
 // row stride is 64 or 192 (mod 256) bytes so the four key rows of a transpose read hit disjoint banks.
 #include "ops.h"
 #include <stdio.h>
+#include <type_traits>
 
 int attention_scalar(const AttentionArgs& a, hipStream_t stream);
 int attention_init();
@@ -45,6 +46,18 @@ template <> struct Mfma32<bf16_t> {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
 };
+
+// max(a, b, c) without the NaN-quieting pre-pass fmaxf gets on matrix-core outputs (scores are finite or -inf)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// max over the two 32-lane halves of the wave, left in every lane (one lane-swap instead of an LDS round trip)
+__device__ __forceinline__ float max_halves(float v) {
+  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return max3f(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
+}
 
 struct FlashParams {
   const char* q; const char* k; const char* v; char* out;
@@ -93,7 +106,8 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : (D <= 80 ? 2 : 1))) void attn_f
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, x = bid & 7;
     const int id = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (bid >> 3);
-    bh = id / p.qblocks;
+    // (the division runs on the vector ALU: tell the compiler that its result is uniform)
+    bh = __builtin_amdgcn_readfirstlane(id / p.qblocks);
     qblk = id - bh * p.qblocks;
   }
   const int b = bh / p.heads, hd = bh - b * p.heads;
@@ -124,31 +138,43 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : (D <= 80 ? 2 : 1))) void attn_f
   u32x4 kreg[G::KC], vreg[G::KC];
   const char* kbase = p.k + ((size_t)b * p.Nk * p.ldk + (size_t)hd * D) * sizeof(T);
   const char* vbase = p.v + ((size_t)b * p.Nk * p.ldv + (size_t)hd * D) * sizeof(T);
-  // chunk geometry of this thread (clamped so every staging register is always written)
-  int ch_key[G::KC], ch_piece[G::KC];
+  // chunk geometry of this thread (clamped so every staging register is always written): byte offsets of its
+  // chunks inside a 64-key tile in global memory and in the two LDS images.  The tile's base address is
+  // uniform (scalar registers), so a load costs no vector address arithmetic.
+  unsigned kgo[G::KC], vgo[G::KC], kso[G::KC], vso[G::KC];
   bool ch_ok[G::KC];
 #pragma unroll
   for (int i = 0; i < G::KC; ++i) {
     const int c = tid + i * 256;
     ch_ok[i] = c < G::NCH;
     const int cc = ch_ok[i] ? c : G::NCH - 1;
-    ch_key[i] = cc / G::CPR;
-    ch_piece[i] = cc - ch_key[i] * G::CPR;
+    const int key = cc / G::CPR, piece = cc - key * G::CPR;
+    kgo[i] = (unsigned)((key * p.ldk + piece * 8) * sizeof(T));
+    vgo[i] = (unsigned)((key * p.ldv + piece * 8) * sizeof(T));
+    kso[i] = key * G::SK + piece * 16;
+    vso[i] = G::KBUF + key * G::SV + piece * 16;
   }
+  const int ntiles = (p.Nk + KV_TILE - 1) / KV_TILE;
+  // K / V of this (batch, head) through buffer descriptors that end with the last key's row: the tile offset
+  // rides in a scalar register, the load needs no vector address arithmetic, and the rows a ragged last tile
+  // reads beyond the sequence come back as zeros (their scores are masked below)
+  const unsigned ktile = (unsigned)(KV_TILE * p.ldk * sizeof(T)), vtile = (unsigned)(KV_TILE * p.ldv * sizeof(T));
+  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)kbase, 0, (int)(((size_t)(p.Nk - 1) * p.ldk + D) * sizeof(T)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)vbase, 0, (int)(((size_t)(p.Nk - 1) * p.ldv + D) * sizeof(T)), 0x00020000);
 #define LOAD_TILE(t_)                                                                                     \
   _Pragma("unroll") for (int i = 0; i < G::KC; ++i) {                                                     \
-    const int row = min((t_) * KV_TILE + ch_key[i], p.Nk - 1);                                            \
-    kreg[i] = *reinterpret_cast<const u32x4*>(kbase + ((size_t)row * p.ldk + ch_piece[i] * 8) * sizeof(T)); \
-    vreg[i] = *reinterpret_cast<const u32x4*>(vbase + ((size_t)row * p.ldv + ch_piece[i] * 8) * sizeof(T)); \
+    kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kgo[i], (t_) * ktile, 0);                        \
+    vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vgo[i], (t_) * vtile, 0);                        \
   }
 #define STORE_TILE(buf_)                                                                                  \
   {                                                                                                       \
-    char* kb_ = smem + (buf_) * G::STAGE;                                                                 \
-    char* vb_ = kb_ + G::KBUF;                                                                            \
+    char* sb_ = smem + (buf_) * G::STAGE;                                                                 \
     _Pragma("unroll") for (int i = 0; i < G::KC; ++i) {                                                   \
       if (ch_ok[i]) {                                                                                     \
-        *reinterpret_cast<u32x4*>(kb_ + ch_key[i] * G::SK + ch_piece[i] * 16) = kreg[i];                  \
-        *reinterpret_cast<u32x4*>(vb_ + ch_key[i] * G::SV + ch_piece[i] * 16) = vreg[i];                  \
+        *reinterpret_cast<u32x4*>(sb_ + kso[i]) = kreg[i];                                                \
+        *reinterpret_cast<u32x4*>(sb_ + vso[i]) = vreg[i];                                                \
       }                                                                                                   \
     }                                                                                                     \
   }
@@ -184,7 +210,6 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : (D <= 80 ? 2 : 1))) void attn_f
     for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int ntiles = (p.Nk + KV_TILE - 1) / KV_TILE;
   LOAD_TILE(0)
   STORE_TILE(0)
   __syncthreads();
@@ -193,9 +218,11 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : (D <= 80 ? 2 : 1))) void attn_f
   // lane i of the group supplies the address of key row i>>2, columns 4*(i&3)..
   const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gcol = ((lane >> 4) & 1) * 16 + gp * 4;
 
-  for (int t = 0; t < ntiles; ++t) {
+  // One key tile; BUF (the LDS buffer it reads, compile time) makes every LDS address an immediate offset.
+  auto tile = [&](auto bufc, const int t) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(bufc)::value;
     if (t + 1 < ntiles) { LOAD_TILE(t + 1) }
-    const char* kb = smem + (t & 1) * G::STAGE;
+    const char* kb = smem + BUF * G::STAGE;
     const char* vb = kb + G::KBUF;
 
     // ---- S^T = K Q^T for the two 32-key blocks ---------------------------------------------------
@@ -233,16 +260,15 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : (D <= 80 ? 2 : 1))) void attn_f
     // The running maximum only moves when some query of the wave outgrows it by more than 2^8: P stays
     // below 256 (exact range of both 16-bit formats, fp32 sums), and almost every tile skips the
     // rescale of the output accumulators.
-    float mx = fmaxf(fmaxf(s0[0], s0[1]), s1[0]);
-    mx = fmaxf(fmaxf(mx, s1[1]), s0[2]);
+    float mx = max3f(s0[0], s0[1], s0[2]), mx1 = max3f(s1[0], s1[1], s1[2]);
 #pragma unroll
-    for (int i = 3; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s0[i]), s0[i + 1 < 16 ? i + 1 : i]);
-#pragma unroll
-    for (int i = 2; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s1[i]), s1[i + 1]);
+    for (int i = 3; i < 15; i += 2) { mx = max3f(mx, s0[i], s0[i + 1]); mx1 = max3f(mx1, s1[i], s1[i + 1]); }
+    mx = max3f(mx, s0[15], s1[15]);
+    mx = max3f(mx, mx1, mx1);
     v8 pf[4];        // P^T fragments: block 0 k-steps 0,1 then block 1 k-steps 0,1
     if constexpr (G::FOLD) {
       // the accumulators already hold score * c - m_run
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = max_halves(mx);
       if (t == 0 || __any(mx > 8.0f)) {
         // first tile: adopt the row maximum; later: move up by the overshoot
         const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
@@ -272,8 +298,7 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : (D <= 80 ? 2 : 1))) void attn_f
         pf[2 + (i >> 3)][i & 7] = (T)e1;
       }
     } else {
-      mx *= p.c;
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = max_halves(mx * p.c);
       if (__any(mx > m_run + 8.0f)) {
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -310,8 +335,16 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : (D <= 80 ? 2 : 1))) void attn_f
       }
     }
 
-    if (t + 1 < ntiles) STORE_TILE((t + 1) & 1)
+    if (t + 1 < ntiles) STORE_TILE(BUF ^ 1)
     __syncthreads();
+  };
+  {
+    int t = 0;
+    for (; t + 1 < ntiles; t += 2) {
+      tile(std::integral_constant<int, 0>{}, t);
+      tile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (t < ntiles) tile(std::integral_constant<int, 0>{}, t);
   }
 
   // ---- normalise and store: lane holds d = 32 dt + 8 (i>>2) + 4 h + (i&3) of its query --------------
@@ -387,6 +420,8 @@ int attention(const AttentionArgs& a, hipStream_t stream) {
     SDMI_TRY(attention_init());
     SDMI_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 4 == 0,
                  "attention: row strides must be multiples of 8 elements");
+    SDMI_REQUIRE((size_t)a.Nk * (size_t)(a.ldk > a.ldv ? a.ldk : a.ldv) * 2 < ((size_t)1 << 31),
+                 "attention: one batch element's K or V spans 2 GiB or more");
     bool handled = false;
     int rc;
     if (a.dtype == SDMI_F16) rc = dispatch_flash<half_t>(a, stream, &handled);

@@ -61,7 +61,38 @@ struct GemmParams {
   int wide_store;     // large-tile kernel: 16-bit output written through the LDS strips
   const float* ln_stats;   // LayerNorm folded in: per row (rstd, rstd * mean); null = plain GEMM
   const float* ln_colsum;  // ... and per column sum_k w[n][k]; `bias` is then b' and is applied after the scaling
+  int ln_nparts;           // 0: ln_stats holds (rstd, rstd * mean) per row; P > 0: P pairs (sum, sum of squares) per
+  float ln_inv_d, ln_eps;  //    row, as a producing GEMM left them (row length 1 / ln_inv_d)
+  float2* rs_out;          // this launch leaves row sums of its OUTPUT for a LayerNorm behind it: rs_parts pairs
+  int rs_parts;            //    (sum, sum of squares of the stored values) per row; null = none
 };
+
+// (rstd, rstd * mean) of row m for a GEMM with a folded LayerNorm
+__device__ __forceinline__ float2 ln_row(const GemmParams& p, int m) {
+  const float2* st = reinterpret_cast<const float2*>(p.ln_stats);
+  if (p.ln_nparts == 0) return st[m];
+  st += (size_t)m * p.ln_nparts;
+  float s, q;
+  if (p.ln_nparts == 1) {
+    s = st[0].x; q = st[0].y;
+  } else {
+    // an even number of pairs, 16 at most: eight 16-byte loads in flight (the ones beyond the row's pairs re-read
+    // its last and count for nothing), summed in slot order
+    const float4* st4 = reinterpret_cast<const float4*>(st);
+    const int last = p.ln_nparts / 2 - 1;
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = st4[min(k, last)];
+    s = 0.f; q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k <= last) { s += v[k].x; q += v[k].y; s += v[k].z; q += v[k].w; }
+    }
+  }
+  const float mean = s * p.ln_inv_d;
+  const float rstd = rsqrtf(fmaxf(q * p.ln_inv_d - mean * mean, 0.f) + p.ln_eps);
+  return make_float2(rstd, rstd * mean);
+}
 
 template <typename T> struct Frag;      // 16 bytes of T as an MFMA operand fragment
 template <> struct Frag<half_t> { typedef half_t type __attribute__((ext_vector_type(8))); };
@@ -90,6 +121,22 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst_wave_base
 }
 
 // Shared epilogue: v[4] are fp32 sums for columns n..n+3 of row m.
+template <typename T>
+__device__ __forceinline__ f32x4 epilogue_value(const GemmParams& p, int m, int n, f32x4 v) {
+  if (p.bias) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+    v += b;
+  }
+  if (p.rowadd) {
+    const int bidx = m / (p.Ho * p.Wo);
+    v += *reinterpret_cast<const f32x4*>(p.rowadd + (size_t)bidx * p.ldra + n);
+  }
+  if (p.resid) {
+    const T* r = reinterpret_cast<const T*>(p.resid) + (size_t)m * p.ldr + n;
+    v.x += to_f32(r[0]); v.y += to_f32(r[1]); v.z += to_f32(r[2]); v.w += to_f32(r[3]);
+  }
+  return v;
+}
 template <typename T>
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, f32x4 v) {
   if (p.bias) {
@@ -139,7 +186,7 @@ __device__ __forceinline__ void ln_fold_acc(const GemmParams& p, f32x4 (&acc)[NI
   float r[MJ], rm[MJ];
 #pragma unroll
   for (int j = 0; j < MJ; ++j) {
-    const float2 st = reinterpret_cast<const float2*>(p.ln_stats)[min(m_lane + 16 * j, p.M - 1)];
+    const float2 st = ln_row(p, min(m_lane + 16 * j, p.M - 1));
     r[j] = st.x; rm[j] = st.y;
   }
 #pragma unroll
@@ -206,9 +253,13 @@ __device__ __forceinline__ void store_wave_tile(const GemmParams& p, f32x4 (&acc
 // (GEGLU gate applied on the way in, the residual on the way out, in fp32, one rounding).  OutT is
 // the stored type: T, or float for split-K slabs and fp32 outputs.  `strip` must hold
 // 16 * (16 * NO + 4) floats, NO = output fragments per row.
+// With `psum` (16 * CH float2 of LDS private to the wave) the wave also leaves the row sums of what it stores,
+// slot `rs_slot` of the rs_parts pairs of every row: a lane sums its pieces, parks the pair in LDS and lanes 0..15
+// fold one row each in piece order.
 template <typename T, typename OutT, int NI, bool G, int MJ = 4>
 __device__ __forceinline__ void store_wave_tile_lds(const GemmParams& p, f32x4 (&acc)[NI][MJ], float* strip,
-                                                    OutT* out, int ldo, int m_wave, int n_wave, int lane) {
+                                                    OutT* out, int ldo, int m_wave, int n_wave, int lane,
+                                                    float2* psum = nullptr, int rs_slot = 0) {
   constexpr int NO = G ? NI / 2 : NI;
   constexpr int ROWF = NO * 16 + 4;
   constexpr int EPC = 16 / (int)sizeof(OutT);   // elements per 16-byte piece
@@ -270,12 +321,31 @@ __device__ __forceinline__ void store_wave_tile_lds(const GemmParams& p, f32x4 (
       Tout o;
 #pragma unroll
       for (int e = 0; e < EPC; ++e) o[e] = from_f32<OutT>(v[e]);
+      if (psum) {
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { const float f = to_f32(o[e]); ps += f; pq = fmaf(f, f, pq); }
+        if (lane + 64 * k < TOTAL) psum[lane + 64 * k] = make_float2(ps, pq);
+      }
       if (lane + 64 * k < TOTAL && m < p.M) {
         *reinterpret_cast<Tout*>(out + (size_t)m * ldo + n_out + c_col[k]) = o;
         if (p.dup_rows > 0) *reinterpret_cast<Tout*>(out + (size_t)(m + p.dup_rows) * ldo + n_out + c_col[k]) = o;
       }
     }
     __builtin_amdgcn_wave_barrier();
+    if (psum) {
+      if (lane < 16) {
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { const float2 v = psum[lane * CH + c]; ps += v.x; pq += v.y; }
+        const int m = m_wave + j * 16 + lane;
+        if (m < p.M) {
+          p.rs_out[(size_t)m * p.rs_parts + rs_slot] = make_float2(ps, pq);
+          if (p.dup_rows > 0) p.rs_out[(size_t)(m + p.dup_rows) * p.rs_parts + rs_slot] = make_float2(ps, pq);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 
@@ -695,13 +765,15 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   {
     const int ncol = n0 + grp * (S::BN / 2) + fq * 4;
     if (ln_mode) {
+      // every lane fetches the statistics of one of the wave's rows; the rows a lane multiplies come by shuffle
+      const float2 mine = ln_row(p, min(m0 + wr * WROWS + (lane % WROWS), p.M - 1));
       float inv[MJ], mean[MJ];
 #pragma unroll
       for (int j = 0; j < MJ; ++j) {
-        const float2 st = reinterpret_cast<const float2*>(p.ln_stats)[min(m0 + wr * WROWS + j * 16 + frow, p.M - 1)];
-        ln_r[j] = st.x;
-        inv[j] = 1.0f / st.x;
-        mean[j] = st.y * inv[j];
+        const float rs = __shfl(mine.x, j * 16 + frow, 64), rm = __shfl(mine.y, j * 16 + frow, 64);
+        ln_r[j] = rs;
+        inv[j] = 1.0f / rs;
+        mean[j] = rm * inv[j];
       }
 #pragma unroll
       for (int i = 0; i < NFW; ++i) {
@@ -820,8 +892,12 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
         store_wave_tile_lds<T, T, NFW, true, MJ>(pe, acc, strip, reinterpret_cast<T*>(p.out), p.ldo, m_wave, n_wave,
                                                  lane);
     } else {
+      // row sums for a LayerNorm behind this GEMM: one slot per (tile along N, wave group)
+      constexpr int STRIPS = 8 * 16 * (16 * NFW + 4) * 4, PSUM = 16 * 2 * NFW * 8;
+      static_assert(STRIPS + 8 * PSUM <= S::LDS_BYTES, "row-sum scratch does not fit");
+      float2* psum = p.rs_out ? reinterpret_cast<float2*>(smem + STRIPS + wid * PSUM) : nullptr;
       store_wave_tile_lds<T, T, NFW, false, MJ>(pe, acc, strip, reinterpret_cast<T*>(p.out), p.ldo, m_wave, n_wave,
-                                                lane);
+                                                lane, psum, 2 * tile_n + grp);
     }
     return;
   }
@@ -846,7 +922,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
         gate += *reinterpret_cast<const f32x4*>(s + 16);
       }
       if (p.ln_stats) {
-        const float2 st = reinterpret_cast<const float2*>(p.ln_stats)[m];
+        const float2 st = ln_row(p, m);
         val = st.x * val + (*reinterpret_cast<const f32x4*>(p.bias + n) - st.y * *reinterpret_cast<const f32x4*>(p.ln_colsum + n));
         gate = st.x * gate + (*reinterpret_cast<const f32x4*>(p.bias + n + 16) -
                               st.y * *reinterpret_cast<const f32x4*>(p.ln_colsum + n + 16));
@@ -861,7 +937,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
       for (int z = 0; z < splits; ++z)
         v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)z * p.M + m) * p.N + n);
       if (p.ln_stats) {
-        const float2 st = reinterpret_cast<const float2*>(p.ln_stats)[m];
+        const float2 st = ln_row(p, m);
         f32x4 b = {0, 0, 0, 0};
         if (p.bias) b = *reinterpret_cast<const f32x4*>(p.bias + n);
         v = st.x * v + (b - st.y * *reinterpret_cast<const f32x4*>(p.ln_colsum + n));
@@ -871,6 +947,66 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
         continue;
       }
       epilogue_store<T>(p, m, n, v);
+    }
+  }
+}
+
+// split-K second pass that also leaves the row sums of its output (one pair per row): a wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(GemmParams p, int splits) {
+  const int lane = threadIdx.x & 63;
+  const int n4 = p.N / 4;
+  for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < p.M; m += gridDim.x * 4) {
+    float ps = 0.f, pq = 0.f;
+    float2 st = make_float2(1.f, 0.f);
+    if (p.ln_stats) st = ln_row(p, m);
+    for (int c = lane; c < n4; c += 64) {
+      const int n = c * 4;
+      f32x4 v = {0, 0, 0, 0};
+      for (int z = 0; z < splits; ++z)
+        v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)z * p.M + m) * p.N + n);
+      GemmParams pe = p;
+      if (p.ln_stats) {
+        f32x4 b = {0, 0, 0, 0};
+        if (p.bias) b = *reinterpret_cast<const f32x4*>(p.bias + n);
+        v = st.x * v + (b - st.y * *reinterpret_cast<const f32x4*>(p.ln_colsum + n));
+        pe.bias = nullptr;
+      }
+      v = epilogue_value<T>(pe, m, n, v);
+      pe.bias = nullptr; pe.rowadd = nullptr; pe.resid = nullptr;
+      epilogue_store<T>(pe, m, n, v);
+      if (!p.out_f32) { v.x = to_f32(from_f32<T>(v.x)); v.y = to_f32(from_f32<T>(v.y)); v.z = to_f32(from_f32<T>(v.z)); v.w = to_f32(from_f32<T>(v.w)); }
+      ps += (v.x + v.y) + (v.z + v.w);
+      pq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    ps = wave_sum(ps); pq = wave_sum(pq);
+    if (lane < p.rs_parts) {
+      const float2 o = lane == 0 ? make_float2(ps, pq) : make_float2(0.f, 0.f);
+      p.rs_out[(size_t)m * p.rs_parts + lane] = o;
+      if (p.dup_rows > 0) p.rs_out[(size_t)(m + p.dup_rows) * p.rs_parts + lane] = o;
+    }
+  }
+}
+
+// row sums of a stored 16-bit / fp32 output, for the launches whose kernel does not leave them itself
+template <typename T>
+__global__ __launch_bounds__(256) void row_sums_kernel(GemmParams p) {
+  const int lane = threadIdx.x & 63;
+  const int n4 = p.N / 4;
+  typedef T Tx4 __attribute__((ext_vector_type(4)));
+  for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < p.M; m += gridDim.x * 4) {
+    float ps = 0.f, pq = 0.f;
+    for (int c = lane; c < n4; c += 64) {
+      const Tx4 r = *reinterpret_cast<const Tx4*>(reinterpret_cast<const T*>(p.out) + (size_t)m * p.ldo + c * 4);
+      const float x = to_f32(r[0]), y = to_f32(r[1]), z = to_f32(r[2]), w = to_f32(r[3]);
+      ps += (x + y) + (z + w);
+      pq += (x * x + y * y) + (z * z + w * w);
+    }
+    ps = wave_sum(ps); pq = wave_sum(pq);
+    if (lane < p.rs_parts) {
+      const float2 o = lane == 0 ? make_float2(ps, pq) : make_float2(0.f, 0.f);
+      p.rs_out[(size_t)m * p.rs_parts + lane] = o;
+      if (p.dup_rows > 0) p.rs_out[(size_t)(m + p.dup_rows) * p.rs_parts + lane] = o;
     }
   }
 }
@@ -1025,6 +1161,15 @@ bool use_tap_inner(const GemmParams& p) {
 // kernel for an explicit split count (callers size the slab with conv_gemm_pick_splits)
 int pick_kind(int M, int N, int K, int dtype, bool geglu) { return make_plan(M, N, K, dtype, geglu).kind; }
 
+int kind_bn(int kind) { return kind == KIND_PP320 ? 320 : (kind == KIND_PP256 ? 256 : (kind == KIND_SMALL ? 128 : 160)); }
+// pairs per row a launch with row_stats_out writes: the large-tile kernels leave one per (tile along N, wave
+// group) from their epilogue, everything else a single one
+int row_stat_parts(int M, int N, int K, int dtype, bool geglu, int splits) {
+  const int kind = pick_kind(M, N, K, dtype, geglu);
+  if (kind == KIND_SMALL || splits > 1 || geglu || dtype == SDMI_F32) return 1;
+  return 2 * (N / kind_bn(kind));
+}
+
 template <typename T, typename S>
 void launch_pp(GemmParams& p, int splits, hipStream_t stream) {
   p.tiles_m = (p.M + S::BM - 1) / S::BM; p.tiles_n = p.N / S::BN;
@@ -1048,6 +1193,12 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   p.M = a.B * a.Ho * a.Wo; p.N = a.N; p.K = a.taps * (p.c0 + p.c1); p.geglu = a.geglu;
   p.dup_rows = a.dup_rows;
   p.ln_stats = a.ln_stats; p.ln_colsum = a.ln_stats ? a.ln_colsum : nullptr;
+  p.ln_nparts = a.ln_nparts; p.ln_eps = a.ln_eps;
+  p.ln_inv_d = 1.0f / (float)(a.taps * (p.c0 + p.c1));
+  p.rs_out = nullptr; p.rs_parts = 0;
+  SDMI_REQUIRE(a.ln_nparts >= 0 && a.ln_nparts <= 16 && (a.ln_nparts == 1 || a.ln_nparts % 2 == 0),
+               "conv_gemm: ln_nparts must be 0, 1 or an even number up to 16");
+  SDMI_REQUIRE(!a.row_stats_out || (!a.geglu && !a.out_f32), "conv_gemm: row sums are not available with GEGLU / fp32 outputs");
   SDMI_REQUIRE(!a.ln_stats || (a.ln_colsum && a.taps == 1 && !a.a1 && !a.rowadd && (!a.geglu || a.bias)),
                "conv_gemm: a folded LayerNorm needs ln_colsum, a single-source pointwise problem without rowadd "
                "(and a bias with GEGLU)");
@@ -1080,6 +1231,9 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   SDMI_TRY(conv_gemm_init());
   p.zero = g_zero_page;
   const int kind = pick_kind(p.M, p.N, p.K, a.dtype, a.geglu != 0);
+  const int rs_parts = a.row_stats_out ? row_stat_parts(p.M, p.N, p.K, a.dtype, a.geglu != 0, a.splits) : 0;
+  // the epilogue leaves the row sums itself when it is the large-tile kernel's wide store (decided below)
+  bool rs_in_kernel = false;
   p.wide_store = a.ldo % 8 == 0 && (!a.resid || a.ldr % 8 == 0) && ((uintptr_t)a.out % 16 == 0) &&
                  (!a.resid || (uintptr_t)a.resid % 16 == 0) && (!p.partial || (uintptr_t)p.partial % 16 == 0) &&
                  !(p.out_f32 && p.geglu) && !direct_store_forced();
@@ -1090,6 +1244,12 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
     ProfScope prof(PROF_CONV_GEMM, stream, 2.0 * p.M * (double)p.N * p.K,
                    ((double)p.M * p.K / (p.taps == 9 ? 9 : 1) + (double)p.N * p.K + (double)p.M * p.N) * sizeof(T),
                    label);
+    if (rs_parts > 0) {
+      p.rs_parts = rs_parts;
+      rs_in_kernel = kind != KIND_SMALL && sizeof(T) == 2 && splits == 1 && p.wide_store &&
+                     rs_parts == 2 * (p.N / kind_bn(kind));
+      if (rs_in_kernel || splits > 1) p.rs_out = reinterpret_cast<float2*>(a.row_stats_out);
+    }
     if constexpr (sizeof(T) == 2) {
       if (kind == KIND_PP320) launch_pp<T, PP320>(p, splits, stream);
       else if (kind == KIND_PP256) launch_pp<T, PP256>(p, splits, stream);
@@ -1108,7 +1268,19 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
     const size_t total = (size_t)p.M * (p.N / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, stream, p, splits);
+    if (p.rs_out && !p.geglu) {
+      int rb = (p.M + 3) / 4;
+      if (rb > 8192) rb = 8192;
+      hipLaunchKernelGGL(splitk_reduce_rows_kernel<T>, dim3(rb), dim3(256), 0, stream, p, splits);
+    } else {
+      hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, stream, p, splits);
+    }
+    SDMI_CHECK_HIP(hipGetLastError());
+  } else if (rs_parts > 0 && !rs_in_kernel) {
+    p.rs_out = reinterpret_cast<float2*>(a.row_stats_out);
+    int rb = (p.M + 3) / 4;
+    if (rb > 8192) rb = 8192;
+    hipLaunchKernelGGL(row_sums_kernel<T>, dim3(rb), dim3(256), 0, stream, p);
     SDMI_CHECK_HIP(hipGetLastError());
   }
   return SDMI_OK;
@@ -1122,3 +1294,7 @@ int conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
 }
 
 int conv_gemm_pick_splits(int M, int N, int K, int dtype, bool geglu) { return make_plan(M, N, K, dtype, geglu).splits; }
+
+int conv_gemm_row_stat_parts(int M, int N, int K, int dtype, bool geglu, int splits) {
+  return row_stat_parts(M, N, K, dtype, geglu, splits);
+}

@@ -50,6 +50,14 @@ struct ConvGemmArgs {
   // layernorm_stats(); the sums become rstd_m * (S_mn - mean_m * colsum_n) + b'_n ahead of the rest of the epilogue
   const float* ln_stats = nullptr;
   const float* ln_colsum = nullptr;
+  // ln_stats in the form a producing GEMM leaves it (row_stats_out below): ln_nparts pairs (sum, sum of squares)
+  // per row, folded and turned into (rstd, rstd * mean) with ln_eps where they are used; 0 = layernorm_stats() form
+  int ln_nparts = 0;
+  float ln_eps = 1e-5f;
+  // not null: the launch also leaves, per output row, conv_gemm_row_stat_parts(...) pairs (sum, sum of squares of
+  // the stored values over the row's N columns) at row_stats_out[row * parts ...] (rows m + dup_rows as well), for a
+  // LayerNorm folded into the GEMM that reads this output.  Not with GEGLU or fp32 outputs.
+  float* row_stats_out = nullptr;
   // > 0: every output row m is also stored at row m + dup_rows of `out` (two samples that are known to
   // be identical so far are computed once); not with GEGLU or fp32 outputs
   int dup_rows = 0;
@@ -58,6 +66,8 @@ int conv_gemm(const ConvGemmArgs& a, hipStream_t stream);
 int conv_gemm_init();   // one-time kernel attribute setup; call outside stream capture
 // smallest split count worth using for this shape on a 256-CU part (1 = no split)
 int conv_gemm_pick_splits(int M, int N, int K, int dtype, bool geglu = false);
+// pairs per row that a launch of this shape with `splits` writes to row_stats_out
+int conv_gemm_row_stat_parts(int M, int N, int K, int dtype, bool geglu, int splits);
 
 // ---- normalisation ---------------------------------------------------------------------------
 struct GroupNormArgs {

@@ -111,6 +111,12 @@ struct sdmi_unet {
   bool fold_ln = false;
   const float* next_ln_stats = nullptr;
   const float* next_ln_colsum = nullptr;
+  int next_ln_nparts = 0;
+  // LayerNorm row sums left by the GEMM that produces the LayerNorm's input (16-bit modes with the fold):
+  // the next gemm() writes them here, last_rs_parts pairs per row
+  bool producer_stats = false;
+  float* next_row_stats_out = nullptr;
+  int last_rs_parts = 0;
 
   // graph replay
   int graph_mode = 1;
@@ -290,6 +296,8 @@ struct sdmi_unet {
     {
       const char* e = getenv("SDMI_LN_FOLD");
       fold_ln = dtype != SDMI_F32 && !(e && atoi(e) == 0);
+      const char* e2 = getenv("SDMI_LN_PRODUCER_STATS");
+      producer_stats = fold_ln && !(e2 && atoi(e2) == 0);
     }
     // scratch for one folded fp32 matrix (the widest is the GEGLU projection, 8d x d) and its bias
     float *fold_w = nullptr, *fold_b = nullptr;
@@ -471,11 +479,13 @@ struct sdmi_unet {
     g.B = B; g.Hin = Hin; g.Win = Win; g.Ho = Ho; g.Wo = Wo; g.taps = pc.taps; g.stride = stride; g.up = up;
     g.N = pc.cout; g.geglu = geglu; g.dtype = dtype;
     g.dup_rows = next_dup_rows; next_dup_rows = 0;
-    g.ln_stats = next_ln_stats; g.ln_colsum = next_ln_colsum;
-    next_ln_stats = next_ln_colsum = nullptr;
+    g.ln_stats = next_ln_stats; g.ln_colsum = next_ln_colsum; g.ln_nparts = next_ln_nparts;
+    next_ln_stats = next_ln_colsum = nullptr; next_ln_nparts = 0;
+    g.row_stats_out = next_row_stats_out; next_row_stats_out = nullptr;
     const int M = B * Ho * Wo, K = pc.taps * (c0 + (a1 ? c1 : 0));
     g.splits = conv_gemm_pick_splits(M, pc.cout, K, dtype, geglu != 0);
     if (g.splits > 1) g.partial = (float*)ws.get("splitk", (size_t)g.splits * M * pc.cout * 4);
+    last_rs_parts = g.row_stats_out ? conv_gemm_row_stat_parts(M, pc.cout, K, dtype, geglu != 0, g.splits) : 0;
     if (ws.dry) return SDMI_OK;
     return conv_gemm(g, s);
   }
@@ -554,20 +564,39 @@ struct sdmi_unet {
     void* nrm = ws.get("nrm", act_bytes(B, H, W, st.ch));
     void* xt = ws.get("xt", (size_t)rows * d * esz);
     void* lnb = fold_ln ? nullptr : ws.get("ln", (size_t)rows * d * esz);
-    float* lnst = fold_ln ? (float*)ws.get("lnstat", (size_t)rows * 2 * 4) : nullptr;
+    // row statistics of xt: (rstd, rstd * mean) from the statistics kernel, or up to 16 (sum, sum of squares) pairs
+    // per row left by the GEMM that wrote xt
+    float* lnst = fold_ln ? (float*)ws.get("lnstat", (size_t)rows * (producer_stats ? 16 : 1) * 2 * 4) : nullptr;
+    int xt_parts = 0, xt_stat_rows = 0;       // what lnst holds for the current xt (0 parts: nothing)
+    // a linear() that (re)writes xt, leaving the row sums behind when the next reader is a folded LayerNorm
+    auto to_xt = [&](const void* a, int K, const PackedConv& pc, int nrows, const void* resid, int dup_rows,
+                     bool read_by_ln = true) -> int {
+      if (producer_stats && read_by_ln) next_row_stats_out = lnst;
+      next_dup_rows = dup_rows;
+      SDMI_TRY(linear(a, K, pc, xt, d, nrows, resid, d, 0, f.s));
+      xt_parts = producer_stats && read_by_ln ? last_rs_parts : 0;
+      xt_stat_rows = nrows + dup_rows;
+      SDMI_REQUIRE(xt_parts <= 16, "row statistics: %d parts per row", xt_parts);
+      return SDMI_OK;
+    };
     void* qkv = ws.get("qkv", (size_t)rows * 3 * d * esz);
     void* att = ws.get("att", (size_t)rows * d * esz);
     void* ffm = ws.get("ffm", (size_t)rows * 4 * d * esz);
     y->p = ws.get(out_role, act_bytes(B, H, W, st.ch)); y->H = H; y->W = W; y->C = st.ch;
     SDMI_TRY(gn(x, nullptr, Bh, st.gn_g, st.gn_b, 1e-6f, 0, nrm, f.s));
-    SDMI_TRY(linear(nrm, st.ch, st.proj_in, xt, d, rows_h, nullptr, 0, 0, f.s));
+    SDMI_TRY(to_xt(nrm, st.ch, st.proj_in, rows_h, nullptr, 0));
     // Linear(LayerNorm(xt)): either the normalised copy goes through HBM (fp32 mode), or only the row statistics
     // do and the GEMM reads xt itself (weights carry gamma, the epilogue applies mean, rstd and W beta)
     auto ln_linear = [&](const TBlockW& tb, int which, const float* colsum, const PackedConv& pc, void* out, int ldo,
                          int nrows, int geglu, int dup_rows) -> int {
       const void* a = xt;
       if (fold_ln) {
-        if (!ws.dry) SDMI_TRY(layernorm_stats(xt, lnst, nrows, d, 1e-5f, dtype, f.s));
+        if (xt_parts > 0 && xt_stat_rows >= nrows) {
+          next_ln_nparts = xt_parts;
+        } else {
+          if (!ws.dry) SDMI_TRY(layernorm_stats(xt, lnst, nrows, d, 1e-5f, dtype, f.s));
+          xt_parts = 0;
+        }
         next_ln_stats = lnst; next_ln_colsum = colsum;
       } else {
         SDMI_TRY(ln(xt, lnb, tb.ln_g[which], tb.ln_b[which], nrows, d, f.s));
@@ -585,16 +614,15 @@ struct sdmi_unet {
       SDMI_TRY(ln_linear(tb, 0, tb.qkv_c, tb.qkv, qkv, 3 * d, rq, 0, 0));
       SDMI_TRY(attn(qkv, 3 * d, (char*)qkv + (size_t)d * esz, 3 * d, (char*)qkv + (size_t)2 * d * esz, 3 * d, att, d,
                     bq, st.heads, N, N, st.dh, f.s));
-      if (half) next_dup_rows = rows_h;
-      SDMI_TRY(linear(att, d, tb.out1, xt, d, rq, xt, d, 0, f.s));
+      SDMI_TRY(to_xt(att, d, tb.out1, rq, xt, half ? rows_h : 0));
       // cross-attention against the cached context projections
       SDMI_TRY(ln_linear(tb, 1, tb.q2_c, tb.q2, qkv, d, rq, 0, half ? rows_h : 0));
       SDMI_TRY(attn(qkv, d, tb.kv_cache, 2 * d, (char*)tb.kv_cache + (size_t)d * esz, 2 * d, att, d, B, st.heads, N,
                     ctx_ntok, st.dh, f.s));
-      SDMI_TRY(linear(att, d, tb.out2, xt, d, rows, xt, d, 0, f.s));
+      SDMI_TRY(to_xt(att, d, tb.out2, rows, xt, 0));
       // GEGLU feed-forward
       SDMI_TRY(ln_linear(tb, 2, tb.ff1_c, tb.ff1, ffm, 4 * d, rows, 1, 0));
-      SDMI_TRY(linear(ffm, 4 * d, tb.ff2, xt, d, rows, xt, d, 0, f.s));
+      SDMI_TRY(to_xt(ffm, 4 * d, tb.ff2, rows, xt, 0, &tb != &st.blocks.back()));
     }
     SDMI_TRY(linear(xt, d, st.proj_out, y->p, st.ch, rows, x.p, st.ch, 0, f.s));
     return SDMI_OK;

@@ -103,6 +103,34 @@ def test_g2_resblocks_through_the_executor(dt):
     assert ea < TOL[dt] and eb < TOL[dt] and eb2 < TOL[dt]
 
 
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_layernorm_row_sums_from_the_producing_gemm(dt, monkeypatch):
+    """In the 16-bit modes the LayerNorms of a transformer block take their row statistics from sums that the GEMM
+    which wrote their input leaves behind (large-tile epilogue, split-K reduction, or a fallback pass, depending on
+    the shape) instead of a pass of their own: same result as with the separate statistics kernel, for a map that
+    takes the large-tile kernels (64x64), one that takes split-K (8x8) and one in between."""
+    sdmi = importlib.import_module("stable-diffusion_amd")
+    cfg = S.sd_v1_unet_config(4)
+    nets = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SDMI_LN_PRODUCER_STATS", flag)
+        net = sdmi.UNetModel(**cfg, compute_dtype=dt)
+        net.load_state_dict(synth.synth_state_dict(net.state_dict_shapes(), 0, device="cuda"))
+        nets.append(net)
+    ctx = g2_u("ctx", (2, 77, 768)).cuda()
+    for name, hw in (("input_blocks.1.1", 64), ("input_blocks.4.1", 20), ("middle_block.1", 8)):
+        idx = _block_index(nets[0], "st", name)
+        ch = {"input_blocks.1.1": 320, "input_blocks.4.1": 640, "middle_block.1": 1280}[name]
+        x = nhwc(synth.normal(5, f"ps.{name}", (2, ch, hw, hw)), dt)
+        ya = nets[0].run_block("st", idx, x, context=ctx)
+        yb = nets[1].run_block("st", idx, x, context=ctx)
+        torch.cuda.synchronize()
+        err = max_rel_err(ya.float().cpu(), yb.float().cpu())
+        print(f"row sums {dt} {name} {hw}x{hw}: {err:.3e}")
+        assert err < TOL[dt]
+    del nets
+
+
 def test_q_sample_and_stochastic_encode_g5_bit_exact():
     """LatentDiffusion.q_sample (:3892-3895) with per-sample timesteps and DDIMSampler.stochastic_encode
     (:5378-5391), both with a timestep per sample and with the one-element tensor of inpaint_with_text.py:260."""

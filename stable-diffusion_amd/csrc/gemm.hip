@@ -563,6 +563,7 @@ typedef PPShape<10, 2, 2> PP320;
 typedef PPShape<8, 2, 2> PP256;
 typedef PPShape<5, 1, 3> PP160;
 typedef PPShape<5, 1, 3, 2> PP160H;     // 128x160: layers whose 256-row tiles would leave CUs idle
+typedef PPShape<4, 1, 3> PP128;         // 256x128: 128-channel layers (the VAE decoder's 512x512 stage)
 
 template <typename T, typename S, bool TI>
 __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
@@ -1036,6 +1037,10 @@ int set_lds_limits() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160H::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160H::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP128, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP128::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP128, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP128::LDS_BYTES));
   }
   return SDMI_OK;
 }
@@ -1064,7 +1069,7 @@ namespace {
 // the workgroups are dealt to the CUs in rounds (512 small blocks or 256 large ones per round), a
 // round takes (K-tiles per split) x (time of one K-tile of that shape), and split-K adds the slab
 // round trip through HBM plus a launch.  The K-tile times are measured on MI355X with full grids.
-enum { KIND_SMALL = 0, KIND_PP320 = 1, KIND_PP256 = 2, KIND_PP160 = 3, KIND_PP160H = 4 };
+enum { KIND_SMALL = 0, KIND_PP320 = 1, KIND_PP256 = 2, KIND_PP160 = 3, KIND_PP160H = 4, KIND_PP128 = 5 };
 struct Plan { int kind, splits; };
 
 // SDMI_GEMM_SHAPE (tests, experiments; read on every call): 1 = 128x128 tiles only, 2 = 256x320 /
@@ -1086,6 +1091,7 @@ constexpr double T_KT_PP320_US = 2.10;    // 256x320x64 K-tile, one block per CU
 constexpr double T_KT_PP256_US = 1.75;    // 256x256x64
 constexpr double T_KT_PP160_US = 1.20;    // 256x160x64
 constexpr double T_KT_PP160H_US = 0.80;   // 128x160x64 (only offered for short K loops, see make_plan)
+constexpr double T_KT_PP128_US = 1.05;    // 256x128x64
 
 double split_cost_us(int M, int N, int splits) {
   if (splits <= 1) return 0.0;
@@ -1117,15 +1123,17 @@ Plan make_plan(int M, int N, int K, int dtype, bool geglu) {
     best_t = (double)((blocks + 511) / 512) * (per + 1.5) * T_KT_SMALL_US + split_cost_us(M, N, best.splits);
   }
   bool found = false;
-  for (int kind = KIND_PP320; kind <= KIND_PP160H; ++kind) {
-    const int bn = kind == KIND_PP320 ? 320 : (kind == KIND_PP256 ? 256 : 160);
+  for (int kind = KIND_PP320; kind <= KIND_PP128; ++kind) {
+    const int bn = kind == KIND_PP320 ? 320 : (kind == KIND_PP256 ? 256 : (kind == KIND_PP128 ? 128 : 160));
     const int bm = kind == KIND_PP160H ? 128 : 256;
     if (N % bn != 0) continue;
     const bool odd = kind == KIND_PP160 || kind == KIND_PP160H;       // odd fragment count: no (value, gate) pairs
     if (odd && (geglu || forced_kind() == 2)) continue;
     if (kind == KIND_PP160H && forced_kind() == 5) continue;
+    // the 128-column shape moves more operand bytes per flop than the wider ones: only where none of them fits
+    if (kind == KIND_PP128 && (N % 160 == 0 || N % 256 == 0)) continue;
     const double tk = kind == KIND_PP320 ? T_KT_PP320_US : (kind == KIND_PP256 ? T_KT_PP256_US :
-                      (kind == KIND_PP160 ? T_KT_PP160_US : T_KT_PP160H_US));
+                      (kind == KIND_PP160 ? T_KT_PP160_US : (kind == KIND_PP128 ? T_KT_PP128_US : T_KT_PP160H_US)));
     const long tiles = (long)((M + bm - 1) / bm) * (N / bn);
     for (int s = 1; s <= 16; ++s) {
       if (s > 1 && nkt / s < 8) break;
@@ -1161,7 +1169,9 @@ bool use_tap_inner(const GemmParams& p) {
 // kernel for an explicit split count (callers size the slab with conv_gemm_pick_splits)
 int pick_kind(int M, int N, int K, int dtype, bool geglu) { return make_plan(M, N, K, dtype, geglu).kind; }
 
-int kind_bn(int kind) { return kind == KIND_PP320 ? 320 : (kind == KIND_PP256 ? 256 : (kind == KIND_SMALL ? 128 : 160)); }
+int kind_bn(int kind) {
+  return kind == KIND_PP320 ? 320 : (kind == KIND_PP256 ? 256 : (kind == KIND_SMALL || kind == KIND_PP128 ? 128 : 160));
+}
 // pairs per row a launch with row_stats_out writes: the large-tile kernels leave one per (tile along N, wave
 // group) from their epilogue, everything else a single one
 int row_stat_parts(int M, int N, int K, int dtype, bool geglu, int splits) {
@@ -1255,6 +1265,7 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
       else if (kind == KIND_PP256) launch_pp<T, PP256>(p, splits, stream);
       else if (kind == KIND_PP160) launch_pp<T, PP160>(p, splits, stream);
       else if (kind == KIND_PP160H) launch_pp<T, PP160H>(p, splits, stream);
+      else if (kind == KIND_PP128) launch_pp<T, PP128>(p, splits, stream);
     }
     if (kind == KIND_SMALL || sizeof(T) != 2) {
       typedef ShapeSmall S;

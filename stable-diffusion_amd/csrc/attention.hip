@@ -1,7 +1,7 @@
 // Flash-style attention on the gfx950 matrix cores (fp16 / bf16 operands, fp32 accumulation and
 // softmax statistics); the score matrix never leaves registers.
 //
-// Work split: one workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries.
+// Work split: one workgroup = 4 (or 8) waves = 128 (256) queries of one (batch, head); each wave owns 32 queries.
 // K/V are walked in tiles of 64 keys, staged global -> registers -> LDS (two LDS buffers, the loads
 // of tile t+1 are issued before the MFMAs of tile t and written after them; one barrier per tile).
 //
@@ -21,6 +21,7 @@
 // row stride is 64 or 192 (mod 256) bytes so the four key rows of a transpose read hit disjoint banks.
 #include "ops.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <type_traits>
 
 int attention_scalar(const AttentionArgs& a, hipStream_t stream);
@@ -75,7 +76,8 @@ template <int D> struct Geo {
   static constexpr int DT = (D + 31) / 32;                // 32-row output tiles of V^T P^T
   static constexpr int CPR = D / 8;                       // 16-byte chunks per K/V row
   static constexpr int NCH = KV_TILE * CPR;               // chunks per tile
-  static constexpr int KC = (NCH + 255) / 256;            // chunks per thread
+  static constexpr int KC = (NCH + 255) / 256;            // chunks per thread of a 4-wave workgroup
+  static constexpr int KC8 = (NCH + 511) / 512;           // ... of an 8-wave workgroup
   // Head sizes that leave spare contraction slots in the last 16-wide step (D % 16 == 8: 40) carry the
   // running maximum through the matrix cores: K rows get two extra columns holding 1, the query fragment
   // the two halves (hi, lo) of -m, and Q is scaled by scale * log2(e) when it is loaded, so that the
@@ -91,9 +93,11 @@ template <int D> struct Geo {
   static constexpr bool ONES = (D % 32) != 0;             // a spare V column exists for the row sums
 };
 
-template <typename T, int D>
-__global__ __launch_bounds__(256, (D <= 40 ? 4 : (D <= 80 ? 2 : 1))) void attn_flash_kernel(FlashParams p) {
+// NW waves per workgroup (4 or 8): 32 * NW queries share every staged K/V tile
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1))) void attn_flash_kernel(FlashParams p) {
   typedef Geo<D> G;
+  constexpr int NT = 64 * NW, KC = (G::NCH + NT - 1) / NT;
   typedef typename Mfma32<T>::v8 v8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : (D <= 80 ? 2 : 1))) void attn_f
     qblk = id - bh * p.qblocks;
   }
   const int b = bh / p.heads, hd = bh - b * p.heads;
-  const int qi = qblk * 128 + wid * 32 + r;
+  const int qi = qblk * (32 * NW) + wid * 32 + r;
   const int qrow = min(qi, p.Nq - 1);
 
   // ---- Q fragments (B operand of K Q^T): dims 16s + 8h .. +7 of this lane's query ---------------
@@ -135,17 +139,17 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : (D <= 80 ? 2 : 1))) void attn_f
   }
 
   // ---- K/V staging -----------------------------------------------------------------------------
-  u32x4 kreg[G::KC], vreg[G::KC];
+  u32x4 kreg[KC], vreg[KC];
   const char* kbase = p.k + ((size_t)b * p.Nk * p.ldk + (size_t)hd * D) * sizeof(T);
   const char* vbase = p.v + ((size_t)b * p.Nk * p.ldv + (size_t)hd * D) * sizeof(T);
   // chunk geometry of this thread (clamped so every staging register is always written): byte offsets of its
   // chunks inside a 64-key tile in global memory and in the two LDS images.  The tile's base address is
   // uniform (scalar registers), so a load costs no vector address arithmetic.
-  unsigned kgo[G::KC], vgo[G::KC], kso[G::KC], vso[G::KC];
-  bool ch_ok[G::KC];
+  unsigned kgo[KC], vgo[KC], kso[KC], vso[KC];
+  bool ch_ok[KC];
 #pragma unroll
-  for (int i = 0; i < G::KC; ++i) {
-    const int c = tid + i * 256;
+  for (int i = 0; i < KC; ++i) {
+    const int c = tid + i * NT;
     ch_ok[i] = c < G::NCH;
     const int cc = ch_ok[i] ? c : G::NCH - 1;
     const int key = cc / G::CPR, piece = cc - key * G::CPR;
@@ -164,14 +168,14 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : (D <= 80 ? 2 : 1))) void attn_f
   const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)vbase, 0, (int)(((size_t)(p.Nk - 1) * p.ldv + D) * sizeof(T)), 0x00020000);
 #define LOAD_TILE(t_)                                                                                     \
-  _Pragma("unroll") for (int i = 0; i < G::KC; ++i) {                                                     \
+  _Pragma("unroll") for (int i = 0; i < KC; ++i) {                                                     \
     kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kgo[i], (t_) * ktile, 0);                        \
     vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vgo[i], (t_) * vtile, 0);                        \
   }
 #define STORE_TILE(buf_)                                                                                  \
   {                                                                                                       \
     char* sb_ = smem + (buf_) * G::STAGE;                                                                 \
-    _Pragma("unroll") for (int i = 0; i < G::KC; ++i) {                                                   \
+    _Pragma("unroll") for (int i = 0; i < KC; ++i) {                                                   \
       if (ch_ok[i]) {                                                                                     \
         *reinterpret_cast<u32x4*>(sb_ + kso[i]) = kreg[i];                                                \
         *reinterpret_cast<u32x4*>(sb_ + vso[i]) = vreg[i];                                                \
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : (D <= 80 ? 2 : 1))) void attn_f
       }
     }
 
-    if (p.causal && t * KV_TILE + KV_TILE - 1 > qblk * 128 + wid * 32) {
+    if (p.causal && t * KV_TILE + KV_TILE - 1 > qblk * (32 * NW) + wid * 32) {
       const int kbase_i = t * KV_TILE + 4 * h;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -388,9 +392,18 @@ int launch_flash(const AttentionArgs& a, hipStream_t stream) {
   p.c = a.scale * 1.4426950408889634f;
   p.causal = a.causal;
   const int lds = 2 * G::STAGE;
-  p.qblocks = (a.Nq + 127) / 128;
+  // d = 40 at 1024..4096 tokens: 8 waves (256 queries) share every staged K/V tile -- half the staging traffic and
+  // barriers per query, measured -5 % at 4096 tokens (16 waves: no better; other head sizes and 9216 tokens: equal or
+  // worse).  SDMI_ATTN_WAVES=4/8 overrides for head sizes up to 80 (experiments; read on every call)
+  int nw = (D == 40 && a.Nq >= 1024 && a.Nq <= 4096 && a.Nk >= 1024) ? 8 : 4;
+  if (const char* e = getenv("SDMI_ATTN_WAVES")) { const int v = atoi(e); if ((v == 4 || v == 8) && D <= 80) nw = v; }
+  p.qblocks = (a.Nq + 32 * nw - 1) / (32 * nw);
   dim3 grid(p.qblocks * a.B * a.heads);
-  hipLaunchKernelGGL((attn_flash_kernel<T, D>), grid, dim3(256), lds, stream, p);
+  if (nw == 8) {
+    if constexpr (D <= 80) hipLaunchKernelGGL((attn_flash_kernel<T, D, 8>), grid, dim3(512), lds, stream, p);
+  } else {
+    hipLaunchKernelGGL((attn_flash_kernel<T, D, 4>), grid, dim3(256), lds, stream, p);
+  }
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }
@@ -436,8 +449,13 @@ template <typename T, int D>
 int init_one() {
   const int lds = 2 * Geo<D>::STAGE;
   if (lds > 48 * 1024)
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_flash_kernel<T, D>,
+  {
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_flash_kernel<T, D, 4>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if constexpr (D <= 80)
+      SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_flash_kernel<T, D, 8>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  }
   return SDMI_OK;
 }
 template <typename T>

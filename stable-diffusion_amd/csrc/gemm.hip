@@ -1074,7 +1074,7 @@ struct Plan { int kind, splits; };
 
 // SDMI_GEMM_SHAPE (tests, experiments; read on every call): 1 = 128x128 tiles only, 2 = 256x320 /
 // 256x256 tiles wherever they are legal, 3 = 256x160 tiles wherever they are legal, 4 = 128x160 likewise,
-// 5 = never 128x160.
+// 5 = never 128x160, 6 = 256x128 wherever it is legal.
 int forced_kind() {
   const char* e = getenv("SDMI_GEMM_SHAPE");
   return e ? atoi(e) : 0;
@@ -1131,7 +1131,7 @@ Plan make_plan(int M, int N, int K, int dtype, bool geglu) {
     if (odd && (geglu || forced_kind() == 2)) continue;
     if (kind == KIND_PP160H && forced_kind() == 5) continue;
     // the 128-column shape moves more operand bytes per flop than the wider ones: only where none of them fits
-    if (kind == KIND_PP128 && (N % 160 == 0 || N % 256 == 0)) continue;
+    if (kind == KIND_PP128 && (N % 160 == 0 || N % 256 == 0) && forced_kind() != 6) continue;
     const double tk = kind == KIND_PP320 ? T_KT_PP320_US : (kind == KIND_PP256 ? T_KT_PP256_US :
                       (kind == KIND_PP160 ? T_KT_PP160_US : (kind == KIND_PP128 ? T_KT_PP128_US : T_KT_PP160H_US)));
     const long tiles = (long)((M + bm - 1) / bm) * (N / bn);
@@ -1142,10 +1142,11 @@ Plan make_plan(int M, int N, int K, int dtype, bool geglu) {
       // measured against 256x160 with split-K it wins up to about 32 K-tiles per workgroup
       if (kind == KIND_PP160H && per > 32 && forced_kind() != 4) continue;
       const double t = (double)((tiles * s + 255) / 256) * (per + 3.0) * tk + split_cost_us(M, N, s);
-      const bool force = (forced_kind() == 2 && !found) || (forced_kind() == 3 && kind == KIND_PP160 && best.kind != kind) ||
-                         (forced_kind() == 4 && kind == KIND_PP160H && best.kind != kind);
-      const bool locked = (forced_kind() == 3 && best.kind == KIND_PP160 && kind != KIND_PP160) ||
-                          (forced_kind() == 4 && best.kind == KIND_PP160H && kind != KIND_PP160H);
+      // forced shapes 3 / 4 / 6: the first legal plan of that kind is taken and only plans of that kind replace it
+      const int want = forced_kind() == 3 ? KIND_PP160 : (forced_kind() == 4 ? KIND_PP160H :
+                       (forced_kind() == 6 ? KIND_PP128 : -1));
+      const bool force = (forced_kind() == 2 && !found) || (kind == want && best.kind != kind);
+      const bool locked = want >= 0 && best.kind == want && kind != want;
       if ((t < best_t && !locked) || force) {
         best_t = t; best.kind = kind; best.splits = s; found = true;
       }

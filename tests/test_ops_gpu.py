@@ -123,6 +123,26 @@ def test_conv2d_tiles_128x160(ops, dt, case, monkeypatch):
     test_conv2d(ops, dt, case)
 
 
+PP128_CASES = [
+    # name, B, H, W, C0, C1, Cout, taps, stride, up, splits   (N a multiple of 128)
+    ("pp128_c128", 2, 24, 24, 128, 0, 128, 9, 1, 0, 1),
+    ("pp128_three_tiles_n_ragged_m", 3, 10, 10, 64, 0, 384, 9, 1, 0, 1),
+    ("pp128_concat_up", 1, 12, 12, 128, 64, 128, 9, 1, 1, 1),
+    ("pp128_down_splitk", 2, 32, 32, 192, 0, 256, 9, 2, 0, 3),
+    ("pp128_pointwise", 1, 24, 24, 256, 0, 640, 1, 1, 0, 1),
+]
+
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("order", ["0", "1"])
+@pytest.mark.parametrize("case", PP128_CASES, ids=[c[0] for c in PP128_CASES])
+def test_conv2d_tiles_256x128(ops, dt, order, case, monkeypatch):
+    """The 256 x 128 shape (the planner's choice for the VAE decoder's 128-channel stage), both K orders."""
+    monkeypatch.setenv("SDMI_GEMM_SHAPE", "6")
+    monkeypatch.setenv("SDMI_GEMM_TAP_INNER", order)
+    test_conv2d(ops, dt, case)
+
+
 @pytest.mark.parametrize("dt", ["fp16", "bf16"])
 @pytest.mark.parametrize("order", ["0", "1"])
 @pytest.mark.parametrize("shape", ["2", "3", "4"])
@@ -284,7 +304,8 @@ def _attn_ref(qv, kv, vv, heads):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("impl", [0, 1])
 @pytest.mark.parametrize("d,Nq,Nk", [(40, 256, 256), (40, 144, 77), (80, 64, 64), (80, 200, 77), (160, 64, 64),
-                                     (160, 36, 77), (40, 1024, 1024)])
+                                     (160, 36, 77), (40, 1024, 1024), (40, 1100, 1100), (40, 1024, 1100),
+                                     (80, 300, 333)])
 def test_attention(ops, dt, impl, d, Nq, Nk):
     heads, B = 8, 2
     C = heads * d

@@ -30,6 +30,7 @@ int attention_init();
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -59,6 +60,20 @@ __device__ __forceinline__ float max_halves(float v) {
   const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return max3f(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
 }
+
+template <typename T> struct Mfma16;
+template <> struct Mfma16<half_t> {
+  typedef half_t v8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ f32x4 mma(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mfma16<bf16_t> {
+  typedef bf16_t v8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ f32x4 mma(v8 a, v8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
 
 struct FlashParams {
   const char* q; const char* k; const char* v; char* out;
@@ -91,6 +106,13 @@ template <int D> struct Geo {
   static constexpr int VBUF = KV_TILE * SV;
   static constexpr int STAGE = KBUF + VBUF;
   static constexpr bool ONES = (D % 32) != 0;             // a spare V column exists for the row sums
+  // The last 32-row output tile holds at most 16 live rows (head dims and the ones column): it is computed as a
+  // 16-row tile with v_mfma_f32_16x16x32 (two query halves x two 32-key steps per tile, 64 matrix-pipe cycles in
+  // place of 128).  The P^T fragments come out of the accumulators laid out for 32x32x16; one
+  // v_permlane16_swap per register pair turns the two k-steps of a 32-key block into the 16x16x32 B operands of the
+  // two query halves (lane rows {q 0-15 | q 16-31} x {keys of half 0 | half 1} -> {q 0-15: four key octets}).
+  static constexpr bool NARROW = ONES && (D % 32) + 1 <= 16;
+  static constexpr int DT32 = NARROW ? DT - 1 : DT;       // full 32-row tiles
 };
 
 // NW waves per workgroup (4 or 8): 32 * NW queries share every staged K/V tile
@@ -207,11 +229,13 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
     }
   }
 
-  f32x16 o[G::DT];
+  f32x16 o[G::DT32 > 0 ? G::DT32 : 1];
 #pragma unroll
-  for (int dt = 0; dt < G::DT; ++dt)
+  for (int dt = 0; dt < G::DT32; ++dt)
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+  // narrow last tile: rows 32 DT32 + 4 (lane / 16) + i of query (lane & 15) [0] and 16 + (lane & 15) [1]
+  f32x4 on[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   float m_run = -INFINITY, l_run = 0.f;
 
   LOAD_TILE(0)
@@ -280,9 +304,13 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
           const float alpha = __builtin_amdgcn_exp2f(-delta);
           l_run *= alpha;
 #pragma unroll
-          for (int dt = 0; dt < G::DT; ++dt)
+          for (int dt = 0; dt < G::DT32; ++dt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+          if constexpr (G::NARROW) {
+            on[0] *= __shfl(alpha, lane & 15, 64);
+            on[1] *= __shfl(alpha, 16 + (lane & 15), 64);
+          }
         }
         m_run = (t == 0 ? 0.f : m_run) + delta;
 #pragma unroll
@@ -309,9 +337,13 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
         m_run = m_new;
         l_run *= alpha;
 #pragma unroll
-        for (int dt = 0; dt < G::DT; ++dt)
+        for (int dt = 0; dt < G::DT32; ++dt)
 #pragma unroll
           for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+        if constexpr (G::NARROW) {
+          on[0] *= __shfl(alpha, lane & 15, 64);
+          on[1] *= __shfl(alpha, 16 + (lane & 15), 64);
+        }
       }
       const float m_new = m_run;
 #pragma unroll
@@ -329,13 +361,37 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
     for (int f = 0; f < 4; ++f) {
       const int key0 = (f >> 1) * 32 + (f & 1) * 16 + 4 * h + gq;      // first 4-key block; second is +8
 #pragma unroll
-      for (int dt = 0; dt < G::DT; ++dt) {
+      for (int dt = 0; dt < G::DT32; ++dt) {
         const char* a0p = vb + key0 * G::SV + (dt * 32 + gcol) * 2;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0p);
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4*)(a0p + 8 * G::SV));
         s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         o[dt] = Mfma32<T>::mma(__builtin_bit_cast(v8, both), pf[f], o[dt]);
+      }
+    }
+
+    if constexpr (G::NARROW) {
+      const int g = lane >> 4;
+#pragma unroll
+      for (int bk = 0; bk < 2; ++bk) {
+        u32x4 xu = __builtin_bit_cast(u32x4, pf[2 * bk]), yu = __builtin_bit_cast(u32x4, pf[2 * bk + 1]);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(xu[w], yu[w], false, false);
+          xu[w] = sw[0]; yu[w] = sw[1];
+        }
+        // lane group g now holds, for query (lane & 15) of either half, the keys 32 bk + 16 (g & 1) + 4 (g >> 1)
+        // + {0..3, 8..11}; the V^T operand is fetched in the same order, rows 32 DT32 + (lane & 15)
+        const int key0 = bk * 32 + (g & 1) * 16 + 4 * (g >> 1) + gq;
+        const char* a0p = vb + key0 * G::SV + (G::DT32 * 32 + gp * 4) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0p);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(a0p + 8 * G::SV));
+        s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const v8 av = __builtin_bit_cast(v8, both);
+        on[0] = Mfma16<T>::mma(av, __builtin_bit_cast(v8, xu), on[0]);
+        on[1] = Mfma16<T>::mma(av, __builtin_bit_cast(v8, yu), on[1]);
       }
     }
 
@@ -352,7 +408,14 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
   }
 
   // ---- normalise and store: lane holds d = 32 dt + 8 (i>>2) + 4 h + (i&3) of its query --------------
-  if constexpr (G::ONES) {
+  if constexpr (G::NARROW) {
+    // the ones column is row D - 32 DT32 of the narrow tile: lanes 16 ((D % 32) / 4) .. of register (D % 32) % 4,
+    // query (lane & 15) of either half
+    constexpr int ROW = D % 32;
+    const float la = __shfl(on[0][ROW % 4], 16 * (ROW / 4) + (lane & 15), 64);
+    const float lb = __shfl(on[1][ROW % 4], 16 * (ROW / 4) + (lane & 15), 64);
+    l_run = (r < 16) ? la : lb;
+  } else if constexpr (G::ONES) {
     // output row D (the ones column) sits in the h = 0 half of the wave, register 4 * ((D % 32) / 8)
     static_assert(D % 8 == 0 && (D % 32) % 8 == 0, "ones column must start an 8-row group");
     l_run = __shfl(o[G::DT - 1][4 * ((D % 32) / 8)], r, 64);
@@ -360,11 +423,11 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
     l_run += __shfl_xor(l_run, 32, 64);
   }
   const float inv = 1.0f / l_run;
+  typedef T Tx4 __attribute__((ext_vector_type(4)));
   if (qi < p.Nq) {
     char* op = p.out + ((size_t)((size_t)b * p.Nq + qi) * p.ldo + (size_t)hd * D) * sizeof(T);
-    typedef T Tx4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int dt = 0; dt < G::DT; ++dt)
+    for (int dt = 0; dt < G::DT32; ++dt)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int d0 = dt * 32 + 8 * g4 + 4 * h;
@@ -374,6 +437,25 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
           *reinterpret_cast<Tx4*>(op + d0 * sizeof(T)) = v;
         }
       }
+  }
+  if constexpr (G::NARROW) {
+    // lane group g holds dims 32 DT32 + 4 g .. +3 of query (lane & 15) [on[0]] and 16 + (lane & 15) [on[1]]
+    const int g = lane >> 4, n = lane & 15;
+    const float inv_a = __shfl(inv, n, 64), inv_b = __shfl(inv, 16 + n, 64);
+    const int d0 = G::DT32 * 32 + 4 * g;
+    if (d0 < D) {
+      const int qbase = qi - r;                       // first query of the wave
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int q = qbase + 16 * half + n;
+        if (q < p.Nq) {
+          const float iv = half ? inv_b : inv_a;
+          char* op = p.out + ((size_t)((size_t)b * p.Nq + q) * p.ldo + (size_t)hd * D) * sizeof(T);
+          Tx4 v = {(T)(on[half][0] * iv), (T)(on[half][1] * iv), (T)(on[half][2] * iv), (T)(on[half][3] * iv)};
+          *reinterpret_cast<Tx4*>(op + d0 * sizeof(T)) = v;
+        }
+      }
+    }
   }
 }
 

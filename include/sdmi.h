@@ -288,7 +288,9 @@ int sdmi_conv_out(const void* x, const float* w, const float* bias, float* wpack
  * callers that want the executor's schedule size `partial` from it.  No counterpart in the reference. */
 int sdmi_conv2d_splits(int m, int n, int k, int dtype);
 /* softmax(q k^T * scale) v per (batch, head)  (CrossAttention :2784-2796).  impl is a bit set:
- * 1 = force the scalar fp32-math kernel, 2 = causal (query i sees keys 0..i: the text transformer's mask) */
+ * 1 = force the scalar fp32-math kernel, 2 = causal (query i sees keys 0..i: the text transformer's mask).
+ * Row strides are multiples of 8 elements for the 16-bit kernels, and one batch element's K (and V) must span
+ * less than 2 GiB (nk * ldk * 2 bytes): the matrix-core kernel addresses them through 32-bit buffer offsets. */
 int sdmi_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
                    int batch, int heads, int nq, int nk, int d, float scale, int dtype, int impl, void* stream);
 /* timestep_embedding :2212-2232 (fp32 out [batch][dim]) */

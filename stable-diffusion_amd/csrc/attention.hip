@@ -91,8 +91,6 @@ template <int D> struct Geo {
   static constexpr int DT = (D + 31) / 32;                // 32-row output tiles of V^T P^T
   static constexpr int CPR = D / 8;                       // 16-byte chunks per K/V row
   static constexpr int NCH = KV_TILE * CPR;               // chunks per tile
-  static constexpr int KC = (NCH + 255) / 256;            // chunks per thread of a 4-wave workgroup
-  static constexpr int KC8 = (NCH + 511) / 512;           // ... of an 8-wave workgroup
   // Head sizes that leave spare contraction slots in the last 16-wide step (D % 16 == 8: 40) carry the
   // running maximum through the matrix cores: K rows get two extra columns holding 1, the query fragment
   // the two halves (hi, lo) of -m, and Q is scaled by scale * log2(e) when it is loaded, so that the

@@ -539,7 +539,8 @@ __global__ __launch_bounds__(S::NTHREADS) void conv_gemm_kernel(GemmParams p) {
 // Wave (wr = wid & 3, grp = wid >> 2) owns rows wr*64..+63 and columns grp*16*NFW.. (NFW fragments);
 // phase (ks, h) multiplies k-step ks of the tile into column part h (NFW/NPH fragments).
 //
-// Shapes: NFW 10 / NPH 2 (256x320) and NFW 8 / NPH 2 (256x256) with two LDS stages; NFW 5 / NPH 1
+// Shapes: NFW 10 / NPH 2 (256x320) and NFW 8 / NPH 1 (256x256: its fragments fit one phase per k-step, 32 MFMAs
+// per segment, +1..3 %) with two LDS stages; NFW 5 / NPH 1
 // (256x160, for layers with too few 256x320 tiles to fill the chip) with three.
 //
 // Hazards.  The stage of K-tile t is read in t's segments; the last reads (group 1, last phase)
@@ -560,7 +561,7 @@ template <int NFW_, int NPH_, int NSTAGE_, int MJ_ = 4> struct PPShape {
   static_assert(LDS_BYTES <= 160 * 1024, "stages do not fit in LDS");
 };
 typedef PPShape<10, 2, 2> PP320;
-typedef PPShape<8, 2, 2> PP256;
+typedef PPShape<8, 1, 2> PP256;
 typedef PPShape<5, 1, 3> PP160;
 typedef PPShape<5, 1, 3, 2> PP160H;     // 128x160: layers whose 256-row tiles would leave CUs idle
 typedef PPShape<4, 1, 3> PP128;         // 256x128: 128-channel layers (the VAE decoder's 512x512 stage)
@@ -838,7 +839,8 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
       for (int i = 0; i < NFP; ++i)
         wf[i] = *reinterpret_cast<const frag_t*>(sb + w_base + (h * NFP + i) * 2048 + coff);
       if (ph == 0 && more) prefetch_a(st_wr);
-      if (ph == 1 && more) prefetch_w(st_wr);
+      // (two stages and two phases: both operands go out in the first phase, a full phase ahead of the wait)
+      if (ph == ((NSTAGE == 2 && 2 * NPH == 2) ? 0 : 1) && more) prefetch_w(st_wr);
       if (ph == 2 * NPH - 1 && grp == 1) {      // the next tile's DMA is retired before the barrier that
         if (keep) wait_keep_one_tile();         // precedes group 0's first read of it
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

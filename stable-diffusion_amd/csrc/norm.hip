@@ -1,7 +1,8 @@
 // GroupNorm(+SiLU) and LayerNorm for NHWC / token-major activations on gfx950.  HBM-bound kernels:
 // 16-byte vector loads/stores, fp32 statistics, double-precision combination of partial sums.
 //
-// GroupNorm runs as two launches:
+// GroupNorm of a small tensor is ONE launch (gn_group_kernel below: a workgroup per (sample, group), the slice
+// held in registers).  Larger tensors take two launches:
 //   1. gn_partial : grid (strips, B); every thread owns one 16-byte channel vector and walks a strip
 //                   of pixels, keeping per-channel sum / sum-of-squares in registers; the block folds
 //                   them into per-group partial sums in LDS (fixed order) and writes [B][strip][G][2].
@@ -227,6 +228,148 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnParams p) {
   }
 }
 
+// One-launch GroupNorm for tensors whose (sample, group) slice fits the registers of one workgroup (every
+// GroupNorm of the UNet): a workgroup owns one (sample, group), reads its HW x cpg elements ONCE, 4 bytes per
+// lane (dpp = 4-byte words per pixel; the block size is a multiple of dpp, so a thread keeps one word column j
+// and walks pixels p0, p0 + pstep, ...; consecutive threads cover consecutive words of the slice), takes the
+// mean and then the centred variance from the registers (two fixed-order folds: lanes, then waves through LDS)
+// and writes the normalised values.  No partial sums leave the workgroup, the tensor is read once instead of
+// twice, and results do not depend on timing.
+struct GnGroupGeo {
+  int dpp, pstep, threads, iters, map;     // map: 0 natural, 1 = a sample's groups on one XCD, 2 = G/8 adjacent groups per XCD
+};
+
+template <typename T, int MAXI>
+__global__ __launch_bounds__(1024) void gn_group_kernel(GnParams p, GnGroupGeo geo) {
+  constexpr int EPD = 4 / (int)sizeof(T);
+  __shared__ float red[2][16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = (int)blockDim.x >> 6;
+  // workgroups go to the XCDs round-robin by id: keep the workgroups that share 128-byte lines (neighbouring
+  // groups of one sample) on one XCD, so that its L2 fetches each line once
+  const int id = blockIdx.x;
+  int b, g;
+  if (geo.map == 1) {
+    const int k = id >> 3;
+    b = (id & 7) + 8 * (k / p.groups); g = k % p.groups;
+  } else if (geo.map == 2) {
+    const int k = id >> 3, gpx = p.groups >> 3;
+    g = (id & 7) * gpx + k % gpx; b = k / gpx;
+  } else {
+    b = id / p.groups; g = id % p.groups;
+  }
+  const int j = t % geo.dpp, p0 = t / geo.dpp;
+  const int c = g * p.cpg + j * EPD;
+  const uint32_t* src; uint32_t rs;       // row stride in 4-byte words
+  if (c < p.c0) { src = reinterpret_cast<const uint32_t*>((const T*)p.x0 + (size_t)b * p.HW * p.c0 + c); rs = p.c0 / EPD; }
+  else { src = reinterpret_cast<const uint32_t*>((const T*)p.x1 + (size_t)b * p.HW * p.c1 + (c - p.c0)); rs = p.c1 / EPD; }
+  uint32_t d[MAXI];
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int px = p0 + i * geo.pstep;
+    d[i] = px < p.HW ? src[(uint32_t)px * rs] : 0u;
+  }
+  auto elem = [](uint32_t w, int e) -> float {
+    if constexpr (EPD == 1) return __builtin_bit_cast(float, w);
+    else return to_f32<T>(__builtin_bit_cast(T, (unsigned short)(e ? (w >> 16) : (w & 0xffffu))));
+  };
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i)
+#pragma unroll
+    for (int e = 0; e < EPD; ++e) s += elem(d[i], e);       // words past the tensor are zero
+  // the registers keep the packed words only: each pass unpacks them again
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) asm volatile("" : "+v"(d[i]));
+  s = wave_sum(s);
+  if (lane == 0) red[0][wave] = s;
+  __syncthreads();
+  float tot = 0.f;
+  for (int w = 0; w < nw; ++w) tot += red[0][w];
+  const float inv_n = 1.0f / ((float)p.cpg * (float)p.HW);
+  const float mean = tot * inv_n;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i)
+    if (p0 + i * geo.pstep < p.HW) {
+#pragma unroll
+      for (int e = 0; e < EPD; ++e) { const float u = elem(d[i], e) - mean; q = fmaf(u, u, q); }
+    }
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) asm volatile("" : "+v"(d[i]));
+  q = wave_sum(q);
+  if (lane == 0) red[1][wave] = q;
+  __syncthreads();
+  float qt = 0.f;
+  for (int w = 0; w < nw; ++w) qt += red[1][w];
+  const float rstd = 1.0f / sqrtf(qt * inv_n + p.eps);
+  float sc[EPD], sh[EPD];
+#pragma unroll
+  for (int e = 0; e < EPD; ++e) {
+    sc[e] = rstd * p.gamma[c + e];
+    sh[e] = fmaf(-mean, sc[e], p.beta[c + e]);
+  }
+  uint32_t* dst = reinterpret_cast<uint32_t*>((T*)p.out + (size_t)b * p.HW * p.C + c);
+  const uint32_t os = p.C / EPD;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int px = p0 + i * geo.pstep;
+    if (px < p.HW) {
+      float y[EPD];
+#pragma unroll
+      for (int e = 0; e < EPD; ++e) {
+        y[e] = fmaf(elem(d[i], e), sc[e], sh[e]);
+        if (p.silu) y[e] = silu_f(y[e]);
+      }
+      uint32_t w;
+      if constexpr (EPD == 1) w = __builtin_bit_cast(uint32_t, y[0]);
+      else w = (uint32_t)__builtin_bit_cast(unsigned short, from_f32<T>(y[0])) |
+               ((uint32_t)__builtin_bit_cast(unsigned short, from_f32<T>(y[EPD - 1])) << 16);
+      dst[(uint32_t)px * os] = w;
+    }
+  }
+}
+
+// Geometry of the one-launch kernel, or threads == 0 when the tensor does not fit it.
+template <typename T>
+GnGroupGeo gn_group_geo(const GnParams& p) {
+  constexpr int EPD = 4 / (int)sizeof(T);
+  GnGroupGeo geo = {0, 0, 0, 0, 0};
+  // A workgroup touches every 128-byte line of its pixels for cpg * sizeof(T) bytes of it; the lines it shares
+  // with the neighbouring groups come through L2 once per group.  Beyond this much line traffic per workgroup
+  // (KiB; measured: slices of the 64x64 level lose, everything smaller gains) the two-launch path is faster.
+  static const long max_line_kib = [] { const char* e = getenv("SDMI_GN_ONE_LAUNCH_KB"); return e ? atol(e) : 256L; }();
+  if (p.cpg % EPD != 0 || p.c0 % EPD != 0 || p.c1 % EPD != 0) return geo;
+  const size_t chunk_bytes = (size_t)p.cpg * sizeof(T);
+  const size_t line_bytes = (size_t)p.HW * (chunk_bytes >= 128 ? chunk_bytes : 128);
+  if (line_bytes > (size_t)max_line_kib * 1024) return geo;
+  if ((size_t)p.HW * (size_t)p.C * sizeof(T) >= ((size_t)1 << 31)) return geo;      // 32-bit word offsets inside a sample
+  const int dpp = p.cpg / EPD;
+  // whole waves and a multiple of dpp: a thread's word column never changes
+  int unit = dpp;
+  while (unit % 64 != 0) unit += dpp;
+  if (unit > 1024) return geo;
+  const int threads = (1024 / unit) * unit, pstep = threads / dpp;
+  const int iters = (p.HW + pstep - 1) / pstep;
+  if (iters > (sizeof(T) == 4 ? 32 : 48)) return geo;      // more words per thread than the registers hold without spilling
+  geo.dpp = dpp; geo.pstep = pstep; geo.threads = threads; geo.iters = iters;
+  geo.map = (p.B % 8 == 0) ? 1 : ((p.groups % 8 == 0) ? 2 : 0);
+  return geo;
+}
+
+template <typename T>
+void launch_gn_group(const GnParams& p, const GnGroupGeo& geo, hipStream_t stream) {
+  const dim3 grid(p.B * p.groups), block(geo.threads);
+#define SDMI_GN_GROUP(MAXI) hipLaunchKernelGGL((gn_group_kernel<T, MAXI>), grid, block, 0, stream, p, geo)
+  if (geo.iters <= 4) SDMI_GN_GROUP(4);
+  else if (geo.iters <= 8) SDMI_GN_GROUP(8);
+  else if (geo.iters <= 12) SDMI_GN_GROUP(12);
+  else if (geo.iters <= 16) SDMI_GN_GROUP(16);
+  else if (geo.iters <= 24) SDMI_GN_GROUP(24);
+  else if (geo.iters <= 32) SDMI_GN_GROUP(32);
+  else SDMI_GN_GROUP(48);
+#undef SDMI_GN_GROUP
+}
+
 template <typename T>
 int launch_gn(const GroupNormArgs& a, hipStream_t stream) {
   constexpr int EPV = VecOf<T>::N;
@@ -241,6 +384,16 @@ int launch_gn(const GroupNormArgs& a, hipStream_t stream) {
                "groupnorm: a %d-element vector may span at most two groups (cpg=%d)", EPV, p.cpg);
   SDMI_REQUIRE(p.B > 0 && p.HW > 0, "groupnorm: empty input");
   p.eps = a.eps; p.gamma = a.gamma; p.beta = a.beta; p.silu = a.silu; p.out = a.out;
+  char label[64];
+  snprintf(label, sizeof(label), "B%d HW%d C%d", p.B, p.HW, p.C);
+  const GnGroupGeo geo = gn_group_geo<T>(p);
+  if (geo.threads) {
+    p.chunks = 0; p.pix_per_chunk = 0; p.partial = nullptr; p.stats = nullptr;
+    ProfScope prof(PROF_GROUPNORM, stream, 0.0, 2.0 * p.B * (double)p.HW * p.C * sizeof(T), label);
+    launch_gn_group<T>(p, geo, stream);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return SDMI_OK;
+  }
   const int nvec = p.C / EPV;
   SDMI_REQUIRE(nvec <= GN_LDS_SLOTS, "groupnorm: C=%d too wide", p.C);
   const int threads = nvec <= 256 ? nvec * (256 / nvec) : 256;
@@ -261,8 +414,6 @@ int launch_gn(const GroupNormArgs& a, hipStream_t stream) {
   p.chunks = (p.HW + p.pix_per_chunk - 1) / p.pix_per_chunk;
   p.partial = a.scratch;
   p.stats = nullptr;
-  char label[64];
-  snprintf(label, sizeof(label), "B%d HW%d C%d", p.B, p.HW, p.C);
   ProfScope prof(PROF_GROUPNORM, stream, 0.0, 2.0 * p.B * (double)p.HW * p.C * sizeof(T), label);
   hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(p.chunks, p.B), dim3(threads), 0, stream, p);
   hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(p.chunks, p.B), dim3(threads), 0, stream, p);

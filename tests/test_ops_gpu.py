@@ -267,7 +267,8 @@ def test_linear_geglu(ops, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("C0,C1,HW", [(320, 0, 16), (128, 0, 24), (1280, 640, 8), (2560, 0, 4), (64, 64, 10)])
+@pytest.mark.parametrize("C0,C1,HW", [(320, 0, 16), (128, 0, 24), (1280, 640, 8), (2560, 0, 4), (64, 64, 10),
+                                      (320, 0, 64), (640, 320, 48), (640, 320, 32)])
 def test_groupnorm(ops, dt, C0, C1, HW):
     C = C0 + C1
     x = q(rnd(f"gn{C0}_{C1}.x", (2, C, HW, HW), -3., 5.), dt)
@@ -280,6 +281,20 @@ def test_groupnorm(ops, dt, C0, C1, HW):
         y = ops.groupnorm(nhwc(x[:, :C0], dt), g.cuda(), b.cuda(), eps, silu=silu,
                           x1=nhwc(x[:, C0:], dt) if C1 else None)
         assert max_rel_err(nchw(y), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,groups", [(1, 32), (3, 32), (8, 32), (16, 32), (5, 4)])
+def test_groupnorm_batches_and_group_counts(ops, dt, B, groups):
+    """Small tensors take the one-launch kernel, whose workgroup -> (sample, group) mapping depends on whether the
+    batch and the group count are multiples of 8; every mapping must cover every (sample, group) once."""
+    C, HW = 640, 12
+    x = q(rnd(f"gnb{B}.x", (B, C, HW, HW), -3., 5.), dt)
+    g = rnd("gnb.g", (C,), 0.5, 1.5)
+    b = rnd("gnb.b", (C,))
+    ref = F.silu(F.group_norm(x, groups, g, b, 1e-5))
+    y = ops.groupnorm(nhwc(x, dt), g.cuda(), b.cuda(), 1e-5, silu=True, groups=groups)
+    assert max_rel_err(nchw(y), ref) < TOL[dt]
 
 
 @pytest.mark.parametrize("dt", DTYPES)

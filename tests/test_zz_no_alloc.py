@@ -36,8 +36,11 @@ def _case(key, B, H, W, C0, C1, dt):
 @pytest.mark.parametrize("dt", [torch.float16, torch.float32])
 def test_static_scratch_groupnorm_equals_workspace_groupnorm(dt):
     before = torch.cuda.memory_allocated()
-    # first call: 16 samples of 32x32x320 (many strips per sample); second: a smaller two-source input
-    for key, shape, eps, silu in (("na.big", (16, 32, 32, 320, 0), 1e-5, True), ("na.small", (2, 8, 8, 640, 320), 1e-6, False)):
+    # the first two calls are large enough for the two-launch kernels, which pass their partial sums through the
+    # scratch buffer: 4 samples of 128x128x320 (many strips per sample), then a smaller two-source input; the last
+    # two are small tensors, which the one-launch kernel serves without touching the buffer
+    for key, shape, eps, silu in (("na.big", (4, 128, 128, 320, 0), 1e-5, True), ("na.concat", (2, 64, 64, 640, 320), 1e-6, False),
+                                  ("na.mid", (16, 32, 32, 320, 0), 1e-5, True), ("na.small", (2, 8, 8, 640, 320), 1e-6, False)):
         x, x1, gamma, beta = _case(key, *shape, dt)
         ref = ops.groupnorm(x, gamma, beta, eps, silu=silu, x1=x1)
         rc, out = _static(x, gamma, beta, eps, silu, x1=x1)

@@ -8,7 +8,8 @@ ops = importlib.import_module("stable-diffusion_amd.ops")
 _lib = importlib.import_module("stable-diffusion_amd._lib")
 lib = _lib.lib()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-for (hw, c) in ((4096, 320), (1024, 640), (256, 1280), (64, 1280), (4096, 640)):
+for (hw, c) in ((4096, 320), (4096, 640), (4096, 960), (1024, 320), (1024, 640), (1024, 960), (1024, 1280), (1024, 1920),
+                (256, 640), (256, 1280), (256, 1920), (256, 2560), (64, 1280), (64, 2560)):
     x = torch.randn(B, hw, 1, c, device="cuda").half()
     g = torch.rand(c, device="cuda") + 0.5; b = torch.randn(c, device="cuda")
     for _ in range(3):

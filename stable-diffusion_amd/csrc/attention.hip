@@ -81,7 +81,7 @@ struct FlashParams {
   int B, heads, Nq, Nk;
   int qblocks;                 // 128-query blocks per (batch, head)
   float c;                     // scale * log2(e)
-  int causal;                  // keys beyond the query's own index are masked
+  int causal;                  // keys beyond the query's own index are masked (selects the kernel variant)
 };
 
 constexpr int KV_TILE = 64;
@@ -114,7 +114,7 @@ template <int D> struct Geo {
 };
 
 // NW waves per workgroup (4 or 8): 32 * NW queries share every staged K/V tile
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, bool CAUSAL>
 __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1))) void attn_flash_kernel(FlashParams p) {
   typedef Geo<D> G;
   constexpr int NT = 64 * NW, KC = (G::NCH + NT - 1) / NT;
@@ -272,7 +272,9 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
       }
     }
 
-    if (p.causal && t * KV_TILE + KV_TILE - 1 > qblk * (32 * NW) + wid * 32) {
+    // the causal mask is a compile-time variant: as a run-time flag the compiler folds it into 32 selects that
+    // every tile of every launch pays
+    if (CAUSAL && t * KV_TILE + KV_TILE - 1 > qblk * (32 * NW) + wid * 32) {
       const int kbase_i = t * KV_TILE + 4 * h;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -477,12 +479,15 @@ int launch_flash(const AttentionArgs& a, hipStream_t stream) {
   // worse).  SDMI_ATTN_WAVES=4/8 overrides for head sizes up to 80 (experiments; read on every call)
   int nw = (D == 40 && a.Nq >= 1024 && a.Nq <= 4096 && a.Nk >= 1024) ? 8 : 4;
   if (const char* e = getenv("SDMI_ATTN_WAVES")) { const int v = atoi(e); if ((v == 4 || v == 8) && D <= 80) nw = v; }
+  if (a.causal) nw = 4;                    // the causal variant exists for 4-wave workgroups only
   p.qblocks = (a.Nq + 32 * nw - 1) / (32 * nw);
   dim3 grid(p.qblocks * a.B * a.heads);
-  if (nw == 8) {
-    if constexpr (D <= 80) hipLaunchKernelGGL((attn_flash_kernel<T, D, 8>), grid, dim3(512), lds, stream, p);
+  if (a.causal) {
+    hipLaunchKernelGGL((attn_flash_kernel<T, D, 4, true>), grid, dim3(256), lds, stream, p);
+  } else if (nw == 8) {
+    if constexpr (D <= 80) hipLaunchKernelGGL((attn_flash_kernel<T, D, 8, false>), grid, dim3(512), lds, stream, p);
   } else {
-    hipLaunchKernelGGL((attn_flash_kernel<T, D, 4>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((attn_flash_kernel<T, D, 4, false>), grid, dim3(256), lds, stream, p);
   }
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
@@ -530,10 +535,12 @@ int init_one() {
   const int lds = 2 * Geo<D>::STAGE;
   if (lds > 48 * 1024)
   {
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_flash_kernel<T, D, 4>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_flash_kernel<T, D, 4, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_flash_kernel<T, D, 4, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if constexpr (D <= 80)
-      SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_flash_kernel<T, D, 8>,
+      SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)attn_flash_kernel<T, D, 8, false>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
   return SDMI_OK;

@@ -919,10 +919,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
       // columns are laid out [16 value | 16 gate] per 32; handle the value quad and fetch its gate
       if ((n & 16) != 0) continue;
       f32x4 val = {0, 0, 0, 0}, gate = {0, 0, 0, 0};
-      for (int z = 0; z < splits; ++z) {
-        const float* s = p.partial + ((size_t)z * p.M + m) * p.N + n;
-        val += *reinterpret_cast<const f32x4*>(s);
-        gate += *reinterpret_cast<const f32x4*>(s + 16);
+      {
+        const float* s0 = p.partial + (size_t)m * p.N + n;
+        const size_t zs = (size_t)p.M * p.N;
+        int z = 0;
+        for (; z + 1 < splits; z += 2) {        // two slabs (four loads) in flight; the sums keep slab order
+          const f32x4 a = *reinterpret_cast<const f32x4*>(s0 + z * zs), ag = *reinterpret_cast<const f32x4*>(s0 + z * zs + 16);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(s0 + (z + 1) * zs), bg = *reinterpret_cast<const f32x4*>(s0 + (z + 1) * zs + 16);
+          val += a; gate += ag; val += b; gate += bg;
+        }
+        for (; z < splits; ++z) {
+          val += *reinterpret_cast<const f32x4*>(s0 + z * zs);
+          gate += *reinterpret_cast<const f32x4*>(s0 + z * zs + 16);
+        }
       }
       if (p.ln_stats) {
         const float2 st = ln_row(p, m);
@@ -937,8 +946,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
       epilogue_store_geglu<T>(p, m, n, n + 16, (n >> 5) * 16 + (n & 15), val, gate);
     } else {
       f32x4 v = {0, 0, 0, 0};
-      for (int z = 0; z < splits; ++z)
-        v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)z * p.M + m) * p.N + n);
+      {
+        const float* s0 = p.partial + (size_t)m * p.N + n;
+        const size_t zs = (size_t)p.M * p.N;
+        int z = 0;
+        for (; z + 3 < splits; z += 4) {        // four slabs in flight; the sum keeps slab order
+          const f32x4 a = *reinterpret_cast<const f32x4*>(s0 + z * zs), b = *reinterpret_cast<const f32x4*>(s0 + (z + 1) * zs);
+          const f32x4 d = *reinterpret_cast<const f32x4*>(s0 + (z + 2) * zs), e = *reinterpret_cast<const f32x4*>(s0 + (z + 3) * zs);
+          v += a; v += b; v += d; v += e;
+        }
+        for (; z < splits; ++z) v += *reinterpret_cast<const f32x4*>(s0 + z * zs);
+      }
       if (p.ln_stats) {
         const float2 st = ln_row(p, m);
         f32x4 b = {0, 0, 0, 0};
@@ -954,22 +972,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
   }
 }
 
-// split-K second pass that also leaves the row sums of its output (one pair per row): a wave per row
+// split-K second pass that also leaves the row sums of its output (one pair per row).  A thread owns ONE quad of
+// columns of one row (all its slab loads are independent and in flight together); a row is TPR threads, a whole
+// number of waves, and its sums are folded lanes first, then the row's waves through LDS in wave order.
 template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(GemmParams p, int splits) {
-  const int lane = threadIdx.x & 63;
+__global__ __launch_bounds__(512) void splitk_reduce_rows_kernel(GemmParams p, int splits, int tpr) {
+  __shared__ float2 wsum[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rpb = (int)blockDim.x / tpr, wpr = tpr >> 6;         // rows per block, waves per row
   const int n4 = p.N / 4;
-  for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < p.M; m += gridDim.x * 4) {
+  const int lr = (int)threadIdx.x / tpr, c = (int)threadIdx.x - lr * tpr;
+  for (int m0 = blockIdx.x * rpb; m0 < p.M; m0 += gridDim.x * rpb) {
+    const int m = m0 + lr;
+    const bool live = m < p.M && c < n4;
     float ps = 0.f, pq = 0.f;
-    float2 st = make_float2(1.f, 0.f);
-    if (p.ln_stats) st = ln_row(p, m);
-    for (int c = lane; c < n4; c += 64) {
+    if (live) {
       const int n = c * 4;
+      const float* src = p.partial + (size_t)m * p.N + n;
+      const size_t zs = (size_t)p.M * p.N;
       f32x4 v = {0, 0, 0, 0};
-      for (int z = 0; z < splits; ++z)
-        v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)z * p.M + m) * p.N + n);
+      int z = 0;
+      for (; z + 3 < splits; z += 4) {           // four slabs in flight; the sum keeps slab order
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + z * zs), b = *reinterpret_cast<const f32x4*>(src + (z + 1) * zs);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(src + (z + 2) * zs), e = *reinterpret_cast<const f32x4*>(src + (z + 3) * zs);
+        v += a; v += b; v += d; v += e;
+      }
+      for (; z < splits; ++z) v += *reinterpret_cast<const f32x4*>(src + z * zs);
       GemmParams pe = p;
       if (p.ln_stats) {
+        const float2 st = ln_row(p, m);
         f32x4 b = {0, 0, 0, 0};
         if (p.bias) b = *reinterpret_cast<const f32x4*>(p.bias + n);
         v = st.x * v + (b - st.y * *reinterpret_cast<const f32x4*>(p.ln_colsum + n));
@@ -979,14 +1010,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(GemmParams p, i
       pe.bias = nullptr; pe.rowadd = nullptr; pe.resid = nullptr;
       epilogue_store<T>(pe, m, n, v);
       if (!p.out_f32) { v.x = to_f32(from_f32<T>(v.x)); v.y = to_f32(from_f32<T>(v.y)); v.z = to_f32(from_f32<T>(v.z)); v.w = to_f32(from_f32<T>(v.w)); }
-      ps += (v.x + v.y) + (v.z + v.w);
-      pq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      ps = (v.x + v.y) + (v.z + v.w);
+      pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     }
     ps = wave_sum(ps); pq = wave_sum(pq);
-    if (lane < p.rs_parts) {
-      const float2 o = lane == 0 ? make_float2(ps, pq) : make_float2(0.f, 0.f);
-      p.rs_out[(size_t)m * p.rs_parts + lane] = o;
-      if (p.dup_rows > 0) p.rs_out[(size_t)(m + p.dup_rows) * p.rs_parts + lane] = o;
+    if (wpr > 1) {
+      if (lane == 0) wsum[wave] = make_float2(ps, pq);
+      __syncthreads();
+      ps = 0.f; pq = 0.f;
+      for (int w = 0; w < wpr; ++w) { const float2 t = wsum[lr * wpr + w]; ps += t.x; pq += t.y; }
+      __syncthreads();
+    }
+    if (m < p.M && c < p.rs_parts) {
+      const float2 o = c == 0 ? make_float2(ps, pq) : make_float2(0.f, 0.f);
+      p.rs_out[(size_t)m * p.rs_parts + c] = o;
+      if (p.dup_rows > 0) p.rs_out[(size_t)(m + p.dup_rows) * p.rs_parts + c] = o;
     }
   }
 }
@@ -1282,12 +1320,20 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
     const size_t total = (size_t)p.M * (p.N / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    if (p.rs_out && !p.geglu) {
-      int rb = (p.M + 3) / 4;
-      if (rb > 8192) rb = 8192;
-      hipLaunchKernelGGL(splitk_reduce_rows_kernel<T>, dim3(rb), dim3(256), 0, stream, p, splits);
+    if (p.rs_out && !p.geglu && p.N / 4 <= 512) {
+      // threads per row: the row's column quads rounded up to whole waves; rows per block: what fits 256 threads
+      const int tpr = ((p.N / 4 + 63) / 64) * 64;
+      const int rpb = tpr >= 256 ? 1 : 256 / tpr;
+      int rb = (p.M + rpb - 1) / rpb;
+      if (rb > 16384) rb = 16384;
+      hipLaunchKernelGGL(splitk_reduce_rows_kernel<T>, dim3(rb), dim3(rpb * tpr), 0, stream, p, splits, tpr);
     } else {
       hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, stream, p, splits);
+      if (p.rs_out && !p.geglu) {               // rows wider than one block: sums from the stored output
+        int rb = (p.M + 3) / 4;
+        if (rb > 8192) rb = 8192;
+        hipLaunchKernelGGL(row_sums_kernel<T>, dim3(rb), dim3(256), 0, stream, p);
+      }
     }
     SDMI_CHECK_HIP(hipGetLastError());
   } else if (rs_parts > 0 && !rs_in_kernel) {

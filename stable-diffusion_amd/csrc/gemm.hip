@@ -565,6 +565,7 @@ typedef PPShape<8, 1, 2> PP256;
 typedef PPShape<5, 1, 3> PP160;
 typedef PPShape<5, 1, 3, 2> PP160H;     // 128x160: layers whose 256-row tiles would leave CUs idle
 typedef PPShape<4, 1, 3> PP128;         // 256x128: 128-channel layers (the VAE decoder's 512x512 stage)
+typedef PPShape<5, 1, 3, 1> PP160Q;     // 64x160: small problems (UNet batch 2) whose 128-row tiles leave most CUs idle
 
 template <typename T, typename S, bool TI>
 __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
@@ -1077,6 +1078,10 @@ int set_lds_limits() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160H::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160H::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160Q, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP160Q::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160Q, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP160Q::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP128, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP128::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP128, true>,
@@ -1109,12 +1114,12 @@ namespace {
 // the workgroups are dealt to the CUs in rounds (512 small blocks or 256 large ones per round), a
 // round takes (K-tiles per split) x (time of one K-tile of that shape), and split-K adds the slab
 // round trip through HBM plus a launch.  The K-tile times are measured on MI355X with full grids.
-enum { KIND_SMALL = 0, KIND_PP320 = 1, KIND_PP256 = 2, KIND_PP160 = 3, KIND_PP160H = 4, KIND_PP128 = 5 };
+enum { KIND_SMALL = 0, KIND_PP320 = 1, KIND_PP256 = 2, KIND_PP160 = 3, KIND_PP160H = 4, KIND_PP128 = 5, KIND_PP160Q = 6 };
 struct Plan { int kind, splits; };
 
 // SDMI_GEMM_SHAPE (tests, experiments; read on every call): 1 = 128x128 tiles only, 2 = 256x320 /
 // 256x256 tiles wherever they are legal, 3 = 256x160 tiles wherever they are legal, 4 = 128x160 likewise,
-// 5 = never 128x160, 6 = 256x128 wherever it is legal.
+// 5 = never 128x160 / 64x160, 6 = 256x128 wherever it is legal, 7 = 64x160 wherever it is legal.
 int forced_kind() {
   const char* e = getenv("SDMI_GEMM_SHAPE");
   return e ? atoi(e) : 0;
@@ -1132,6 +1137,7 @@ constexpr double T_KT_PP256_US = 1.75;    // 256x256x64
 constexpr double T_KT_PP160_US = 1.20;    // 256x160x64
 constexpr double T_KT_PP160H_US = 0.80;   // 128x160x64 (only offered for short K loops, see make_plan)
 constexpr double T_KT_PP128_US = 1.05;    // 256x128x64
+constexpr double T_KT_PP160Q_US = 0.55;   // 64x160x64 (short K loops only, like 128x160)
 
 double split_cost_us(int M, int N, int splits) {
   if (splits <= 1) return 0.0;
@@ -1163,17 +1169,18 @@ Plan make_plan(int M, int N, int K, int dtype, bool geglu) {
     best_t = (double)((blocks + 511) / 512) * (per + 1.5) * T_KT_SMALL_US + split_cost_us(M, N, best.splits);
   }
   bool found = false;
-  for (int kind = KIND_PP320; kind <= KIND_PP128; ++kind) {
+  for (int kind = KIND_PP320; kind <= KIND_PP160Q; ++kind) {
     const int bn = kind == KIND_PP320 ? 320 : (kind == KIND_PP256 ? 256 : (kind == KIND_PP128 ? 128 : 160));
-    const int bm = kind == KIND_PP160H ? 128 : 256;
+    const int bm = kind == KIND_PP160H ? 128 : (kind == KIND_PP160Q ? 64 : 256);
     if (N % bn != 0) continue;
-    const bool odd = kind == KIND_PP160 || kind == KIND_PP160H;       // odd fragment count: no (value, gate) pairs
+    const bool odd = kind == KIND_PP160 || kind == KIND_PP160H || kind == KIND_PP160Q;   // odd fragment count: no (value, gate) pairs
     if (odd && (geglu || forced_kind() == 2)) continue;
-    if (kind == KIND_PP160H && forced_kind() == 5) continue;
+    if ((kind == KIND_PP160H || kind == KIND_PP160Q) && forced_kind() == 5) continue;
     // the 128-column shape moves more operand bytes per flop than the wider ones: only where none of them fits
     if (kind == KIND_PP128 && (N % 160 == 0 || N % 256 == 0) && forced_kind() != 6) continue;
     const double tk = kind == KIND_PP320 ? T_KT_PP320_US : (kind == KIND_PP256 ? T_KT_PP256_US :
-                      (kind == KIND_PP160 ? T_KT_PP160_US : (kind == KIND_PP128 ? T_KT_PP128_US : T_KT_PP160H_US)));
+                      (kind == KIND_PP160 ? T_KT_PP160_US : (kind == KIND_PP128 ? T_KT_PP128_US :
+                      (kind == KIND_PP160Q ? T_KT_PP160Q_US : T_KT_PP160H_US))));
     const long tiles = (long)((M + bm - 1) / bm) * (N / bn);
     for (int s = 1; s <= 16; ++s) {
       if (s > 1 && nkt / s < 8) break;
@@ -1181,10 +1188,12 @@ Plan make_plan(int M, int N, int K, int dtype, bool geglu) {
       // the 128-row shape pays its extra weight traffic back only while the per-tile fixed cost dominates:
       // measured against 256x160 with split-K it wins up to about 32 K-tiles per workgroup
       if (kind == KIND_PP160H && per > 32 && forced_kind() != 4) continue;
+      // the 64-row shape likewise, and sooner: measured ahead of 128x160 up to about 16 K-tiles per workgroup
+      if (kind == KIND_PP160Q && per > 16 && forced_kind() != 7) continue;
       const double t = (double)((tiles * s + 255) / 256) * (per + 3.0) * tk + split_cost_us(M, N, s);
-      // forced shapes 3 / 4 / 6: the first legal plan of that kind is taken and only plans of that kind replace it
+      // forced shapes 3 / 4 / 6 / 7: the first legal plan of that kind is taken and only plans of that kind replace it
       const int want = forced_kind() == 3 ? KIND_PP160 : (forced_kind() == 4 ? KIND_PP160H :
-                       (forced_kind() == 6 ? KIND_PP128 : -1));
+                       (forced_kind() == 6 ? KIND_PP128 : (forced_kind() == 7 ? KIND_PP160Q : -1)));
       const bool force = (forced_kind() == 2 && !found) || (kind == want && best.kind != kind);
       const bool locked = want >= 0 && best.kind == want && kind != want;
       if ((t < best_t && !locked) || force) {
@@ -1307,6 +1316,7 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
       else if (kind == KIND_PP160) launch_pp<T, PP160>(p, splits, stream);
       else if (kind == KIND_PP160H) launch_pp<T, PP160H>(p, splits, stream);
       else if (kind == KIND_PP128) launch_pp<T, PP128>(p, splits, stream);
+      else if (kind == KIND_PP160Q) launch_pp<T, PP160Q>(p, splits, stream);
     }
     if (kind == KIND_SMALL || sizeof(T) != 2) {
       typedef ShapeSmall S;

@@ -123,6 +123,14 @@ def test_conv2d_tiles_128x160(ops, dt, case, monkeypatch):
     test_conv2d(ops, dt, case)
 
 
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("case", PP_CASES, ids=[c[0] for c in PP_CASES])
+def test_conv2d_tiles_64x160(ops, dt, case, monkeypatch):
+    """Same cases through the 64 x 160 shape (one row fragment per wave; small problems at UNet batch 2)."""
+    monkeypatch.setenv("SDMI_GEMM_SHAPE", "7")
+    test_conv2d(ops, dt, case)
+
+
 PP128_CASES = [
     # name, B, H, W, C0, C1, Cout, taps, stride, up, splits   (N a multiple of 128)
     ("pp128_c128", 2, 24, 24, 128, 0, 128, 9, 1, 0, 1),
@@ -145,7 +153,7 @@ def test_conv2d_tiles_256x128(ops, dt, order, case, monkeypatch):
 
 @pytest.mark.parametrize("dt", ["fp16", "bf16"])
 @pytest.mark.parametrize("order", ["0", "1"])
-@pytest.mark.parametrize("shape", ["2", "3", "4"])
+@pytest.mark.parametrize("shape", ["2", "3", "4", "7"])
 def test_large_tiles_both_k_orders(ops, dt, order, shape, monkeypatch):
     """3x3 convolutions through the tap-major and the tap-inner K walk of every large-tile shape: concat
     sources, stride 2, ragged M, split-K (splits start mid-slice), long K, the encoder's asymmetric padding."""
@@ -163,7 +171,7 @@ def test_large_tiles_both_k_orders(ops, dt, order, shape, monkeypatch):
 
 
 @pytest.mark.parametrize("dt", ["fp16", "bf16"])
-@pytest.mark.parametrize("shape", ["2", "3", "4"])
+@pytest.mark.parametrize("shape", ["2", "3", "4", "7"])
 def test_large_tiles_direct_store_path(ops, dt, shape, monkeypatch):
     """The store path for outputs that are not 16-byte addressable (straight from the accumulator layout)."""
     monkeypatch.setenv("SDMI_GEMM_SHAPE", shape)
@@ -173,7 +181,7 @@ def test_large_tiles_direct_store_path(ops, dt, shape, monkeypatch):
 
 
 @pytest.mark.parametrize("dt", ["fp16", "bf16"])
-@pytest.mark.parametrize("shape", ["2", "3", "4"])
+@pytest.mark.parametrize("shape", ["2", "3", "4", "7"])
 def test_large_tiles_long_k(ops, dt, shape, monkeypatch):
     """Many K-tiles across taps and both concat sources: ring wrap-around and segment changes."""
     monkeypatch.setenv("SDMI_GEMM_SHAPE", shape)
@@ -192,7 +200,7 @@ def test_large_tiles_epilogues(ops, dt, monkeypatch):
     res = q(rnd("ppepi.res", (B, Cout, H, W)), dt)
     ref = F.conv2d(x, w, b, padding=1) + emb[:, :, None, None] + res
     wp = ops.pack_weight(w.cuda(), dt)
-    for shape in ("2", "3", "4"):
+    for shape in ("2", "3", "4", "7"):
         monkeypatch.setenv("SDMI_GEMM_SHAPE", shape)
         for splits in (1, 2):
             y = ops.conv2d(nhwc(x, dt), wp, b.cuda(), taps=9, rowadd=emb.cuda(), resid=nhwc(res, dt), splits=splits)

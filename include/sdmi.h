@@ -232,14 +232,16 @@ int sdmi_inpaint_composite(const void* image, const void* mask, const void* pred
  * token-major in the given dtype unless stated.
  * ------------------------------------------------------------------------------------------ */
 /* GroupNorm32 :2266 / Normalize :32 (+ optional SiLU); x1 may be NULL; scratch: fp32 device buffer
- * of sdmi_groupnorm_scratch_bytes(batch, groups) bytes. */
+ * of sdmi_groupnorm_scratch_bytes(batch, groups) bytes (the two launches of a large tensor exchange their
+ * partial sums through it; a tensor whose (sample, group) slices fit a workgroup's registers is normalised
+ * in one launch that leaves it untouched). */
 int64_t sdmi_groupnorm_scratch_bytes(int batch, int groups);
 int sdmi_groupnorm(const void* x0, int c0, const void* x1, int c1, int batch, int hw, int groups, float eps,
                    const float* gamma, const float* beta, int silu, void* out, void* scratch, int dtype,
                    void* stream);
 /* sdmi_groupnorm for callers that cannot allocate or bring a workspace: code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments and the
- * same results bit for bit, minus `scratch`: the partial sums the two launches exchange live in a buffer
+ * same results bit for bit, minus `scratch`: the partial sums the two launches of a large tensor exchange live in a buffer
  * built into the library (a device array of 2 MiB + 8 KiB, one copy per GPU, held until the process ends),
  * which limits a call to batch <= 32 and groups <= 32; larger calls fail with SDMI_EINVAL and a message.
  * The call makes no hipMalloc / hipFree and calls no allocating routine.  All calls on one GPU share that

@@ -551,13 +551,17 @@ __global__ __launch_bounds__(S::NTHREADS) void conv_gemm_kernel(GemmParams p) {
 template <int NFW_, int NPH_, int NSTAGE_, int MJ_ = 4> struct PPShape {
   static constexpr int NFW = NFW_, NPH = NPH_, NSTAGE = NSTAGE_, MJ = MJ_;   // MJ: 16-row fragments per wave
   static constexpr int NFP = NFW / NPH;                             // fragments per phase
+  // one row fragment per wave: a K-tile is so little matrix work (2 NFW MFMAs per wave) that the two-group
+  // schedule's eight synchronisations cost more than they hide; every wave runs read -> multiply -> one barrier
+  static constexpr bool LOCKSTEP = MJ_ == 1;
+  static_assert(!LOCKSTEP || NSTAGE_ <= 5, "the lock-step loop keeps at most three tiles in flight behind the next one");
   static constexpr int BM = 64 * MJ, BN = 32 * NFW, NTHREADS = 512;
   static constexpr int AP = MJ;                                     // 1-KiB activation pieces per wave and tile
   static constexpr int WPT = BN / 8, WP_LO = WPT / 8, WP_REM = WPT % 8;   // weight pieces: waves < WP_REM take one more
   static constexpr int WP_MAX = WP_LO + (WP_REM ? 1 : 0);
   static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE_BYTES = A_BYTES + W_BYTES;
   static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
-  static_assert(NFW % NPH == 0 && (NSTAGE == 2 || NSTAGE == 3), "unsupported shape");
+  static_assert(NFW % NPH == 0 && (NSTAGE == 2 || NSTAGE == 3 || LOCKSTEP), "unsupported shape");
   static_assert(LDS_BYTES <= 160 * 1024, "stages do not fit in LDS");
 };
 typedef PPShape<10, 2, 2> PP320;
@@ -753,6 +757,16 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AP + S::WP_LO) : "memory");
   };
 
+  // ... at most n tiles' worth (n <= 3, deeper rings of the lock-step loop)
+  auto wait_keep_tiles = [&](int n) {
+    const int e = wp_extra ? 1 : 0;
+    constexpr int PER = AP + S::WP_LO;
+    if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (n == 1) { if (e) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER + 1) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory"); }
+    else if (n == 2) { if (e) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER + 2) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory"); }
+    else { if (e) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER + 3) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory"); }
+  };
+
   const int frow = lane & 15, fq = lane >> 4;
   // The accumulators start from the per-column bias and the per-(sample, column) time-embedding term
   // (when this launch owns the epilogue): their loads overlap the first tile's DMA and the epilogue
@@ -817,12 +831,48 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
 #pragma unroll
   for (int t = 0; t < NSTAGE - 1; ++t)
     if (t < nk) { prefetch_a(t); prefetch_w(t); }
-  if (NSTAGE == 3 && nk > 1) wait_keep_one_tile();
+  if constexpr (S::LOCKSTEP) wait_keep_tiles(min(NSTAGE - 2, nk - 1));
+  else if (NSTAGE == 3 && nk > 1) wait_keep_one_tile();
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if (grp == 1) __builtin_amdgcn_s_barrier();
+  if (!S::LOCKSTEP && grp == 1) __builtin_amdgcn_s_barrier();
 
   int st_rd = 0, st_wr = NSTAGE - 1;          // stage of the tile being multiplied / of the tile being fetched
+  if constexpr (S::LOCKSTEP) {
+    // All waves in step, one barrier per K-tile: read the tile's fragments, put tile kt + NSTAGE - 1 in flight (its
+    // stage held tile kt - 1, whose reads every wave retired before the barrier that ended that iteration),
+    // multiply, wait for this wave's share of tile kt + 1, barrier.
+    static_assert(NPH == 1, "lock-step loop reads whole k-steps");
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* sb = smem + st_rd * S::STAGE_BYTES;
+      const bool more = kt + NSTAGE - 1 < nk;
+      frag_t af2[2][MJ], wf2[2][NFW];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int coff = ((4 * ks + fq) ^ sw) * 16;
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) af2[ks][j] = *reinterpret_cast<const frag_t*>(sb + a_base + j * 2048 + coff);
+#pragma unroll
+        for (int i = 0; i < NFW; ++i) wf2[ks][i] = *reinterpret_cast<const frag_t*>(sb + w_base + i * 2048 + coff);
+      }
+      if (more) { prefetch_a(st_wr); prefetch_w(st_wr); }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < NFW; ++i)
+#pragma unroll
+          for (int j = 0; j < MJ; ++j) acc[i][j] = mma(wf2[ks][i], af2[ks][j], acc[i][j]);
+      // tile kt + 1 must have landed; the tiles issued after it (NSTAGE - 2 of them in the steady state) stay in flight
+      wait_keep_tiles(min(nk - 1, kt + NSTAGE - 1) - (kt + 1));
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      st_rd = st_rd + 1 == NSTAGE ? 0 : st_rd + 1;
+      st_wr = st_wr + 1 == NSTAGE ? 0 : st_wr + 1;
+    }
+  } else {
   for (int kt = 0; kt < nk; ++kt) {
     const char* sb = smem + st_rd * S::STAGE_BYTES;
     const bool more = kt + NSTAGE - 1 < nk;           // a tile to put in flight during this one
@@ -869,6 +919,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
     st_wr = st_wr + 1 == NSTAGE ? 0 : st_wr + 1;
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
+  }
 
   GemmParams pe = p;
   if (own_epilogue) { pe.bias = nullptr; pe.rowadd = nullptr; }      // already in the accumulators

@@ -551,9 +551,9 @@ __global__ __launch_bounds__(S::NTHREADS) void conv_gemm_kernel(GemmParams p) {
 template <int NFW_, int NPH_, int NSTAGE_, int MJ_ = 4> struct PPShape {
   static constexpr int NFW = NFW_, NPH = NPH_, NSTAGE = NSTAGE_, MJ = MJ_;   // MJ: 16-row fragments per wave
   static constexpr int NFP = NFW / NPH;                             // fragments per phase
-  // one row fragment per wave: a K-tile is so little matrix work (2 NFW MFMAs per wave) that the two-group
+  // one or two row fragments per wave: a K-tile is so little matrix work (2 NFW MJ MFMAs per wave) that the two-group
   // schedule's eight synchronisations cost more than they hide; every wave runs read -> multiply -> one barrier
-  static constexpr bool LOCKSTEP = MJ_ == 1;
+  static constexpr bool LOCKSTEP = MJ_ <= 2;
   static_assert(!LOCKSTEP || NSTAGE_ <= 5, "the lock-step loop keeps at most three tiles in flight behind the next one");
   static constexpr int BM = 64 * MJ, BN = 32 * NFW, NTHREADS = 512;
   static constexpr int AP = MJ;                                     // 1-KiB activation pieces per wave and tile

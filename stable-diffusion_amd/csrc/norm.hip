@@ -407,7 +407,7 @@ int launch_gn(const GroupNormArgs& a, hipStream_t stream) {
   if (chunks > GN_MAX_CHUNKS) chunks = GN_MAX_CHUNKS;
   // every second-pass block folds its sample's chunk partials before it starts: with few samples a long
   // list costs more (serial round trips) than the extra blocks gain
-  static const int chunk_cap = [] { const char* e = getenv("SDMI_GN_CHUNK_CAP"); return e ? atoi(e) : 64; }();
+  static const int chunk_cap = [] { const char* e = getenv("SDMI_GN_CHUNK_CAP"); return e ? atoi(e) : 128; }();
   if (chunks > chunk_cap) chunks = chunk_cap;
   if (chunks < 1) chunks = 1;
   p.pix_per_chunk = (p.HW + chunks - 1) / chunks;

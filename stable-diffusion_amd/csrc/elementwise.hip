@@ -38,7 +38,7 @@ constexpr int SL_PASSES = 2;       // passes per wave
 constexpr int SL_THREADS = 1024;   // 16 waves share one LDS copy of x: enough loads in flight per CU
 constexpr int SL_WAVES = SL_THREADS / 64;
 
-template <int MB>
+template <int MB, int NPW = SL_NPW, int PASSES = SL_PASSES>
 __global__ __launch_bounds__(SL_THREADS) void small_linear_kernel(const float* x, const float* W, const float* bias,
                                                                   float* y, int M, int K, int N, int act_in,
                                                                   int act_out) {
@@ -52,29 +52,29 @@ __global__ __launch_bounds__(SL_THREADS) void small_linear_kernel(const float* x
       sl_x[m * K + k] = v;
     }
   __syncthreads();
-  for (int pass = 0; pass < SL_PASSES; ++pass) {
-    const int n0 = ((blockIdx.x * SL_PASSES + pass) * SL_WAVES + wave) * SL_NPW;
+  for (int pass = 0; pass < PASSES; ++pass) {
+    const int n0 = ((blockIdx.x * PASSES + pass) * SL_WAVES + wave) * NPW;
     if (n0 >= N) return;
-    float acc[SL_NPW][MB];
+    float acc[NPW][MB];
 #pragma unroll
-    for (int j = 0; j < SL_NPW; ++j)
+    for (int j = 0; j < NPW; ++j)
 #pragma unroll
       for (int m = 0; m < MB; ++m) acc[j][m] = 0.f;
     for (int k = lane * 4; k < K; k += 256) {
-      float4 w[SL_NPW];
+      float4 w[NPW];
 #pragma unroll
-      for (int j = 0; j < SL_NPW; ++j)
+      for (int j = 0; j < NPW; ++j)
         w[j] = *reinterpret_cast<const float4*>(W + (size_t)min(n0 + j, N - 1) * K + k);
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
         const float4 xv = *reinterpret_cast<const float4*>(sl_x + m * K + k);
 #pragma unroll
-        for (int j = 0; j < SL_NPW; ++j)
+        for (int j = 0; j < NPW; ++j)
           acc[j][m] += xv.x * w[j].x + xv.y * w[j].y + xv.z * w[j].z + xv.w * w[j].w;
       }
     }
 #pragma unroll
-    for (int j = 0; j < SL_NPW; ++j)
+    for (int j = 0; j < NPW; ++j)
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
         const float sum = wave_sum(acc[j][m]);
@@ -340,6 +340,19 @@ int small_linear(const float* x, const float* W, const float* bias, float* y, in
   SDMI_TRY(elementwise_init());
   const int per_block = SL_WAVES * SL_NPW * SL_PASSES;
   const dim3 block(SL_THREADS);
+  // few output columns (the time-embedding MLP: 1280): one weight row per wave and one pass, or 10 workgroups would
+  // stream the whole matrix
+  if (M <= 2 && N <= 4096) {
+    SDMI_REQUIRE((size_t)2 * K * 4 <= SMALL_LINEAR_MAX_LDS, "small_linear: K=%d too large", K);
+    if (M == 1)
+      hipLaunchKernelGGL((small_linear_kernel<1, 1, 1>), dim3((N + SL_WAVES - 1) / SL_WAVES, 1), block, (size_t)K * 4, s,
+                         x, W, bias, y, M, K, N, act_in, act_out);
+    else
+      hipLaunchKernelGGL((small_linear_kernel<2, 1, 1>), dim3((N + SL_WAVES - 1) / SL_WAVES, 1), block, (size_t)2 * K * 4,
+                         s, x, W, bias, y, M, K, N, act_in, act_out);
+    SDMI_CHECK_HIP(hipGetLastError());
+    return SDMI_OK;
+  }
 #define SL_LAUNCH(MB_)                                                                                    \
   {                                                                                                       \
     SDMI_REQUIRE((size_t)(MB_) * K * 4 <= SMALL_LINEAR_MAX_LDS, "small_linear: K=%d too large", K);     \

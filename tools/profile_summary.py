@@ -75,6 +75,8 @@ def classify(k):
         return "gn_partial"
     if "gn_apply" in k:
         return "gn_apply"
+    if "gn_group" in k:
+        return "gn_group (one launch)"
     if "layernorm" in k:
         return "layernorm"
     return None

@@ -305,6 +305,23 @@ def test_groupnorm_batches_and_group_counts(ops, dt, B, groups):
     assert max_rel_err(nchw(y), ref) < TOL[dt]
 
 
+@pytest.mark.parametrize("shape", [(16, 32, 640, 0), (16, 32, 1280, 0), (8, 32, 1280, 640), (4, 32, 2560, 0),
+                                   (16, 16, 1280, 0), (16, 8, 1280, 1280), (16, 64, 320, 0)],
+                         ids=lambda s: "x".join(str(v) for v in s))
+def test_groupnorm_unet_sizes(ops, shape):
+    """GroupNorm + SiLU at the UNet's batch-16 tensor sizes: every register budget of the one-launch kernel (8 to 48
+    words per thread), the sample-per-XCD workgroup mapping, a two-source input, and the two-launch path (64 x 64)."""
+    B, HW, C0, C1 = shape
+    C = C0 + C1
+    x = q(rnd(f"gnfull{HW}_{C0}_{C1}.x", (B, C, HW, HW), -3., 5.), "fp16")
+    g = rnd("gnfull.g", (C,), 0.5, 1.5)
+    b = rnd("gnfull.b", (C,))
+    ref = F.silu(F.group_norm(x, 32, g, b, 1e-5))
+    y = ops.groupnorm(nhwc(x[:, :C0], "fp16"), g.cuda(), b.cuda(), 1e-5, silu=True,
+                      x1=nhwc(x[:, C0:], "fp16") if C1 else None)
+    assert max_rel_err(nchw(y), ref) < TOL["fp16"]
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("d", [320, 640, 1280, 512])
 def test_layernorm(ops, dt, d):

@@ -68,6 +68,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-clip", action="store_true", help="feed (B,77,768) context tensors instead of running "
                     "the text transformer on token ids inside the step")
+    ap.add_argument("--no-parity", action="store_true", help="skip the one extra batch that is held against the "
+                    "reference's 50-step image after the timed region")
+    ap.add_argument("--fp32-cost", action="store_true", help="also time the fp32 compute mode (UNet batch 2, and a "
+                    "batch at 1 and 3 DDIM steps extrapolated to the full count)")
     ap.add_argument("--no-c2", action="store_true", help="skip the batch-2 UNet timing (keeps the kernel "
                     "population of a profiled run identical to the roofline pass)")
     return ap.parse_args()
@@ -106,13 +110,29 @@ def pmc_traffic():
     """(HBM bytes per launch of the dominant kernel, file it came from) from the newest committed rocprofv3 --pmc
     summary (tools/profile_round.sh: counters need passes of their own, so this run cannot measure them)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    import re
+    def round_of(path):
+        m = re.match(r"r(\d+)_", os.path.basename(path))
+        return int(m.group(1)) if m else -1
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=round_of, reverse=True):
         try:
             with open(path) as f:
                 return json.load(f).get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
         except (OSError, ValueError):
             continue
     return None, None
+
+
+def pmc_traffic_classes():
+    """Per shape class of the dominant kernel ("conv3x3", "pointwise"): the entries of the same committed summary."""
+    path = pmc_traffic()[1]
+    if not path:
+        return {}
+    try:
+        with open(os.path.join(ROOT, path)) as f:
+            return json.load(f).get("classes") or {}
+    except (OSError, ValueError):
+        return {}
 
 
 def cpu_baseline(ddim_steps, size, with_clip=True):
@@ -167,14 +187,34 @@ def log(rank, msg):
     print(f"[bench rank {rank} +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def visible_gpu_count():
+    """GPUs this process could open, counted without any HIP / torch.cuda call: the KFD topology nodes that have
+    SIMDs, capped by the *_VISIBLE_DEVICES lists.  An upper bound (a container may see nodes it cannot open); a rank
+    that finds no device of its own still fails on its own and its code is relayed."""
+    import glob
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(path) as f:
+                for line in f:
+                    if line.startswith("simd_count ") and int(line.split()[1]) > 0:
+                        n += 1
+        except (OSError, ValueError):
+            continue
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if var in os.environ:
+            n = min(n, len([e for e in os.environ[var].split(",") if e.strip()]))
+    return n
+
+
 def spawn_ranks(args):
-    """Parent of a multi-rank run that was not started by torchrun: start the ranks as a child process (this
-    process has made no GPU call and makes none), pass the rank-0 JSON line through and return the child's code."""
+    """Parent of a multi-rank run that was not started by torchrun: start the ranks as a child process, pass the
+    rank-0 JSON line through and return the child's code.  This process makes no torch.cuda / HIP call at all: devices
+    are counted from sysfs and the environment."""
     import socket
     import subprocess
-    share = os.environ.get("SDMI_BENCH_SHARE_DEVICE") == "1"
-    have = torch.cuda.device_count()              # counting devices does not initialise the GPU
-    if have < args.gpus and not share:
+    have = visible_gpu_count()
+    if have < args.gpus and os.environ.get("SDMI_BENCH_SHARE_DEVICE") != "1":
         print(f"bench.py: --gpus {args.gpus} but only {have} device(s) are visible", file=sys.stderr)
         return 2
     with socket.socket() as sk:
@@ -244,9 +284,14 @@ def main():
         return pipeline.initial_latents(n, h, h, dev, first_sample=first), uc, c
     inputs = {first: batch_inputs(first, n) for first, n in pipeline.sample_batches(lo, hi, B)}
 
+    last = {}
+
     def run_batch(first, n):
+        # decoded images leave the step as the uint8 HWC array the reference's script saves (txt2img.py:307-317):
+        # that is what the ranks gather
         x_T, uc, c = inputs[first]
-        img, _ = pipeline.txt2img(model, x_T, uc, c, steps=args.ddim_steps, scale=args.scale, sampler=sampler)
+        img, last["z"] = pipeline.txt2img(model, x_T, uc, c, steps=args.ddim_steps, scale=args.scale, sampler=sampler,
+                                          as_uint8=True)
         return img
 
     def local_step():
@@ -265,19 +310,46 @@ def main():
         step()
     fence()
     log(rank, f"{args.warmup} warmup step(s) done, timing {args.steps}")
+    # SDMI_BENCH_LABELS=path (profiling runs, eager mode): the per-launch shape labels of the timed steps, in launch
+    # order, so that a counter pass over the same command can be split by shape class
+    labels_path = os.environ.get("SDMI_BENCH_LABELS") if args.no_graph and rank == 0 else None
+    if labels_path:
+        lib.sdmi_prof_reset()
+        lib.sdmi_prof_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     fence()
     elapsed = time.perf_counter() - t0
     log(rank, f"timed region {elapsed:.3f} s")
+    if labels_path:
+        lib.sdmi_prof_enable(0)
+        _lib.check(lib.sdmi_prof_dump(labels_path.encode()), "prof_dump")
+        lib.sdmi_prof_reset()
     if world > 1:
         tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    assert out.shape[0] == total and bool(torch.isfinite(out).all())
+    assert out.shape[0] == total and out.dtype == torch.uint8 and bool(torch.isfinite(last["z"]).all())
+    assert 0 < int(out.max()) and int(out.min()) < 255, "degenerate images"
     images = total * args.steps
     value = images / elapsed
+
+    # the gather on its own (it is also inside the timed region): same payload, 5 repetitions, max over ranks
+    per_rank = (total + world - 1) // world
+    collective = {"op": "all_gather_into_tensor of the uint8 images", "backend": None, "ranks": 1,
+                  "bytes_per_rank": int(per_rank * out[0].numel() * out.element_size()), "ms": 0.0}
+    if world > 1:
+        parts = local_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            pipeline.gather_sharded(parts, total, rank, world)
+        fence()
+        tg = torch.tensor([(time.perf_counter() - t0) / 5], device=dev if backend == "nccl" else "cpu",
+                          dtype=torch.float64)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        collective.update(backend=dist.get_backend(), ranks=dist.get_world_size(), ms=1e3 * float(tg.item()))
 
     result = {
         "metric": "images/sec (node) 512x512 50-step DDIM CFG; UNet it/s at batch 2",
@@ -293,7 +365,10 @@ def main():
                                " + UNet loop + fused CFG/DDIM update + VAE decode + clamp; SD-v1-shaped random weights",
                    "global_batch": total, "latent": [4, h, h], "parallelism": f"replicas x{world} (sample shard)",
                    "graph_replay": not args.no_graph},
+        "collective": collective,
     }
+    if rank == 0 and not args.no_graph:
+        result["unet_launches_per_forward"] = {f"batch{2 * B}_sampler_mode": unet.graph_launches()}
 
     if rank == 0 and not args.no_c2:
         # ---- C2: single UNet forward, batch 2 -------------------------------------------------------
@@ -314,12 +389,78 @@ def main():
         result["unet_it_per_s_batch2"] = 1.0 / dt2
         result["unet_batch2_ms"] = 1e3 * dt2
         result["unet_batch2_tflops"] = 2 * UNET_GFLOP_PER_SAMPLE / dt2 / 1e3
+        if not args.no_graph:
+            result["unet_launches_per_forward"]["batch2"] = unet.graph_launches()
         # whole-step algorithmic rate
         if args.size == 512:
             # whole-step rate on the work actually executed (the CFG-pair shortcut's skipped layers are not counted)
             per_image = (2 * UNET_GFLOP_PER_SAMPLE - CFG_PAIR_SKIPPED_GFLOP) * args.ddim_steps + VAE_GFLOP_PER_IMAGE
             result["step_tflops"] = total * per_image / 1e3 / (elapsed / args.steps)
             result["step_tflop_executed"] = total * per_image / 1e3
+
+    if rank == 0 and not args.no_parity and args.size == 512 and args.ddim_steps == 50 and args.scale == 7.5 \
+            and args.dtype != "fp32":
+        # ---- the timed sequence against the reference: one more batch through exactly the path the timed region
+        # ran (same batch, 50 steps, graph replay, sampler promises), in which slots 0 and 5 carry the x_T and the
+        # conditioning of the reference's own 50-step trajectory (tests/golden/g7_c3_traj.npz, made by running the
+        # unmodified reference on these weights): PSNR of slot 0 against the reference's image, and slots 0 and 5
+        # must come out identical.  Outside the timed region.
+        log(rank, "parity of the timed sequence against the reference's 50-step image")
+        import numpy as np
+        gz = np.load(os.path.join(ROOT, "tests", "golden", "g7_c3_traj.npz"), allow_pickle=False)
+        gt = lambda k: torch.from_numpy(np.asarray(gz[k])).float().to(dev)
+        x_T = pipeline.initial_latents(B, h, h, dev).clone()
+        uc, c = pipeline.synthetic_conditioning(B, dev)
+        uc, c = uc.clone(), c.clone()
+        for slot in (0, 5 % B):
+            x_T[slot], uc[slot], c[slot] = gt("x_T")[0], gt("uc")[0], gt("c")[0]
+        img, _ = pipeline.txt2img(model, x_T, uc, c, steps=50, scale=7.5, sampler=sampler)
+        torch.cuda.synchronize()
+        ref = gt("image")[0]
+        mse = float(((img[0].double() - ref.double()) ** 2).mean())
+        result["parity_psnr_db"] = 99.0 if mse == 0 else float(10.0 * np.log10(1.0 / mse))
+        result["parity_slots_identical"] = bool(torch.equal(img[0], img[5 % B]))
+        result["parity_reference"] = "tests/golden/g7_c3_traj.npz (the reference's fp32 CPU image of the same weights)"
+        del img, x_T, uc, c
+
+    if rank == 0 and args.fp32_cost and args.dtype != "fp32":
+        # ---- what the drop-in default (fp32 compute, the reference's use_fp16=False) costs on the same box ----
+        log(rank, "fp32 mode: UNet batch 2 and a reduced-step batch")
+        m32 = pipeline.build_synthetic_model(4, "crossattn", "fp32", device=dev)
+        u32 = m32.model.diffusion_model
+        x2 = pipeline.initial_latents(1, h, h, dev).repeat(2, 1, 1, 1).contiguous()
+        uc2, c2 = pipeline.synthetic_conditioning(1, dev)
+        ctx2 = torch.cat([uc2, c2])
+        t2 = torch.full((2,), 981, dtype=torch.int64, device=dev)
+        o2 = torch.empty_like(x2)
+        for _ in range(3):
+            u32(x2, t2, context=ctx2, out=o2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            u32(x2, t2, context=ctx2, out=o2)
+        torch.cuda.synchronize()
+        result["fp32_unet_batch2_ms"] = 1e3 * (time.perf_counter() - t0) / 5
+        S32 = 3
+        s32 = sdmi.DDIMSampler(m32)
+        xT = pipeline.initial_latents(B, h, h, dev)
+        uc8, c8 = pipeline.synthetic_conditioning(B, dev)
+        def run32(steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pipeline.txt2img(m32, xT, uc8, c8, steps=steps, scale=args.scale, sampler=s32)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        run32(1)
+        t1, t3 = run32(1), run32(S32)
+        per_step = (t3 - t1) / (S32 - 1)          # one UNet batch-16 call + update
+        fixed = t1 - per_step                      # VAE decode + clamp
+        result["fp32_images_per_s"] = B / (args.ddim_steps * per_step + fixed)
+        result["fp32_note"] = (f"fp32 compute mode (the drop-in default): batch {B}, measured at 1 and {S32} DDIM steps "
+                               f"({1e3 * per_step:.1f} ms per step, {1e3 * fixed:.1f} ms decode) and extrapolated to "
+                               f"{args.ddim_steps} steps; every step is the same UNet call")
+        del m32, u32, s32
+        torch.cuda.empty_cache()
 
     if rank == 0 and not args.no_roofline:
         log(rank, "roofline pass")
@@ -343,7 +484,21 @@ def main():
         raw_us, dom_fl = sum(r[2] for r in dom), sum(r[3] for r in dom)
         dom_us = max(raw_us - cal.value * len(dom), 1e-9)
         achieved = dom_fl / (dom_us * 1e-6) / 1e12 if dom else 0.0
+        def shape_class(rows_):
+            us = max(sum(r[2] for r in rows_) - cal.value * len(rows_), 1e-9)
+            fl = sum(r[3] for r in rows_)
+            tf = fl / (us * 1e-6) / 1e12 if rows_ else 0.0
+            return {"achieved": tf, "frac": tf / peak, "launches": len(rows_), "kernel_ms_per_step": us * 1e-3,
+                    "avg_launch_us": us / max(1, len(rows_)), "flops_per_launch": fl / max(1, len(rows_)),
+                    "algorithmic_bytes_per_launch": sum(r[4] for r in rows_) / max(1, len(rows_))}
+        conv3 = shape_class([r for r in dom if " t9 " in r[1]])
+        point = shape_class([r for r in dom if " t1 " in r[1]])
+        tr = pmc_traffic_classes()
+        for cls, name in ((conv3, "conv3x3"), (point, "pointwise")):
+            cls["traffic"] = (tr.get(name) or {}).get("hbm_bytes_per_launch")
+            cls["sustained_clock_GHz"] = (tr.get(name) or {}).get("shader_clock_GHz")
         result["roofline"] = {
+            "conv3x3": conv3, "pointwise": point,
             "bound": "mfma", "kernel": DOMINANT_NAME.format(elem={"fp16": "half", "bf16": "bfloat16"}.get(args.dtype, "float")),
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic()[0],
             "traffic_source": pmc_traffic()[1],

@@ -105,6 +105,9 @@ int sdmi_unet_set_cfg_duplicate(sdmi_unet* u, int enable);
 int64_t sdmi_unet_device_bytes(const sdmi_unet* u);
 /* 1: replay the forward as a captured HIP graph when shapes and pointers repeat (default), 0: eager. */
 int sdmi_unet_set_graph_mode(sdmi_unet* u, int enable);
+/* Kernel launches in the currently recorded forward graph (0 while none is recorded): what one replayed
+ * UNetModel.forward :3519-3552 costs in launches. */
+int sdmi_unet_graph_launches(const sdmi_unet* u);
 void sdmi_unet_destroy(sdmi_unet* u);
 
 /* ------------------------------------------------------------------------------------------
@@ -133,6 +136,10 @@ int sdmi_ddpm_step(const void* x, const void* eps, float sqrt_recip_acp, float s
 int sdmi_q_sample_blend(const void* x0, const void* noise, const void* mask, const void* img, float sqrt_acp,
                         float sqrt_one_minus_acp, void* out, int batch, int channels, int hw, int mask_channels,
                         void* stream);
+/* The guidance combine of p_sample_ddim :5347 alone: out = e_uncond + scale * (e_cond - e_uncond), eps =
+ * [e_uncond | e_cond] (2n floats).  For callers that modify the combined score (score_corrector, :5351-5353)
+ * before the update; sdmi_ddim_step with cfg = 0 then takes the result. */
+int sdmi_cfg_combine(const void* eps, float scale, void* out, int64_t n, void* stream);
 /* out = ca * a + cb * b */
 int sdmi_axpby(const void* a, const void* b, float ca, float cb, void* out, int64_t n, void* stream);
 
@@ -246,7 +253,10 @@ int sdmi_groupnorm(const void* x0, int c0, const void* x1, int c1, int batch, in
  * which limits a call to batch <= 32 and groups <= 32; larger calls fail with SDMI_EINVAL and a message.
  * The call makes no hipMalloc / hipFree and calls no allocating routine.  All calls on one GPU share that
  * GPU's buffer: calls that overlap in time on one GPU (different streams) race; calls on one stream are safe.
- * Nothing in the buffer needs clearing between calls (the first launch writes every word the second reads). */
+ * Nothing in the buffer needs clearing between calls (the first launch writes every word the second reads).
+ * The buffer's address on a GPU is looked up once per GPU: by the finalize call of any model handle on that
+ * GPU, otherwise by the first call of this entry point there, which must then happen outside stream capture
+ * (later calls may be captured). */
 int sdmi_groupnorm_static(const void* x0, int c0, const void* x1, int c1, int batch, int hw, int groups, float eps,
                           const float* gamma, const float* beta, int silu, void* out, int dtype, void* stream);
 /* nn.LayerNorm (:2807-2809) over the last dim */

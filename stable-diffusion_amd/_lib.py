@@ -53,6 +53,7 @@ SIGNATURES = {
                                     c_int, c_void_p]),
     "sdmi_unet_device_bytes": (c_int64, [c_void_p]),
     "sdmi_unet_set_graph_mode": (c_int, [c_void_p, c_int]),
+    "sdmi_unet_graph_launches": (c_int, [c_void_p]),
     "sdmi_unet_set_uniform_timesteps": (c_int, [c_void_p, c_int]),
     "sdmi_unet_set_cfg_duplicate": (c_int, [c_void_p, c_int]),
     "sdmi_unet_destroy": (None, [c_void_p]),
@@ -60,6 +61,7 @@ SIGNATURES = {
                                c_void_p, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     "sdmi_ddpm_step": (c_int, [c_void_p, c_void_p, c_float, c_float, c_int, c_float, c_float, c_float, c_void_p,
                                c_float, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sdmi_cfg_combine": (c_int, [c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "sdmi_axpby": (c_int, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_int64, c_void_p]),
     "sdmi_q_sample_blend": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_int, c_int,
                                     c_int, c_int, c_void_p]),

@@ -136,6 +136,10 @@ int sdmi_ddpm_step(const void* x, const void* eps, float sqrt_recip_acp, float s
                    (hipStream_t)stream);
 }
 
+int sdmi_cfg_combine(const void* eps, float scale, void* out, int64_t n, void* stream) {
+  return cfg_combine((const float*)eps, scale, (float*)out, n, (hipStream_t)stream);
+}
+
 int sdmi_axpby(const void* a, const void* b, float ca, float cb, void* out, int64_t n, void* stream) {
   return axpby((const float*)a, (const float*)b, ca, cb, (float*)out, n, (hipStream_t)stream);
 }

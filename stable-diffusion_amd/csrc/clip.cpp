@@ -63,6 +63,7 @@ struct sdmi_clip_text {
     SDMI_TRY(store.check_complete(specs));
     SDMI_TRY(conv_gemm_init());
     SDMI_TRY(attention_init());
+    SDMI_TRY(groupnorm_static_init());
     const int d = cfg.hidden, f = cfg.intermediate;
     const size_t esz = sdmi_dtype_size(dtype);
     std::vector<std::string> drop;

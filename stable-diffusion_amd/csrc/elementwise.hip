@@ -145,6 +145,16 @@ __global__ void ddim_step_kernel(const float* x, const float* eps, int cfg, floa
   }
 }
 
+// classifier-free-guidance combine on its own (e_uncond + scale * (e_cond - e_uncond), :5347), for callers that
+// put a score corrector between the combine and the update
+__global__ void cfg_combine_kernel(const float* eps, float scale, float* out, int64_t n) {
+#pragma clang fp contract(off)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float eu = eps[i], ec = eps[n + i];
+    out[i] = eu + scale * (ec - eu);
+  }
+}
+
 // DDPM ancestral update: x0 from eps, the posterior mean of q(x_{t-1} | x_t, x0) and the noise term.
 // The per-timestep table entries arrive as scalars (the sampling loops use one t for the whole batch).
 __global__ void ddpm_step_kernel(const float* x, const float* eps, float c_recip, float c_recipm1, int clip,
@@ -384,6 +394,11 @@ int elementwise_init() {
                                      (int)SMALL_LINEAR_MAX_LDS));
   SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)small_linear_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)SMALL_LINEAR_MAX_LDS));
+  // the narrow-output instantiations park up to two rows of x (K beyond 8192 exceeds the default 64 KiB)
+  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)small_linear_kernel<1, 1, 1>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMALL_LINEAR_MAX_LDS));
+  SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)small_linear_kernel<2, 1, 1>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMALL_LINEAR_MAX_LDS));
   done = true;
   return SDMI_OK;
 }
@@ -439,6 +454,13 @@ int q_sample_blend(const float* x0, const float* noise, const float* mask, const
                mask_channels, C);
   hipLaunchKernelGGL(q_sample_blend_kernel, dim3(grid_for((size_t)B * C * HW, 256, 2048)), dim3(256), 0, s, x0, noise,
                      mask, img, ca, cb, out, B, C, HW, mask_channels);
+  SDMI_CHECK_HIP(hipGetLastError());
+  return SDMI_OK;
+}
+
+int cfg_combine(const float* eps, float scale, float* out, int64_t n, hipStream_t s) {
+  SDMI_REQUIRE(eps && out && n > 0, "cfg_combine: bad arguments");
+  hipLaunchKernelGGL(cfg_combine_kernel, dim3(grid_for((size_t)n, 256, 2048)), dim3(256), 0, s, eps, scale, out, n);
   SDMI_CHECK_HIP(hipGetLastError());
   return SDMI_OK;
 }

@@ -602,6 +602,24 @@ float* g_gn_static_ptr[GN_MAX_DEVICES];          // device address of `scratch` 
 std::mutex g_gn_static_mu;
 }  // namespace
 
+// Resolve the current device's copy of `scratch` (once per device).  hipGetSymbolAddress sets the device variable
+// up lazily, which must not first happen inside a stream capture: the model handles call this from finalize, and a
+// caller that uses the entry point on its own makes its first call per GPU outside capture.
+int groupnorm_static_init(float** out) {
+  int dev = -1;
+  SDMI_CHECK_HIP(hipGetDevice(&dev));
+  SDMI_REQUIRE(dev >= 0 && dev < GN_MAX_DEVICES, "groupnorm_static: device ordinal %d not supported", dev);
+  std::lock_guard<std::mutex> lock(g_gn_static_mu);
+  if (!g_gn_static_ptr[dev]) {
+    void* sym = nullptr;
+    SDMI_CHECK_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)));     // this device's copy of the array
+    SDMI_REQUIRE(sym != nullptr, "groupnorm_static: the scratch symbol has no address on device %d", dev);
+    g_gn_static_ptr[dev] = (float*)sym;
+  }
+  if (out) *out = g_gn_static_ptr[dev];
+  return SDMI_OK;
+}
+
 int groupnorm_static(const GroupNormArgs& a_in, hipStream_t stream) {
   SDMI_REQUIRE(a_in.B > 0 && a_in.B <= GN_STATIC_MAX_BATCH,
                "groupnorm_static: batch %d is beyond the built-in scratch (at most %d samples per call; use "
@@ -611,20 +629,8 @@ int groupnorm_static(const GroupNormArgs& a_in, hipStream_t stream) {
                GN_STATIC_MAX_GROUPS);
   SDMI_REQUIRE(groupnorm_scratch_floats(a_in.B, a_in.HW, a_in.groups) <= GN_STATIC_FLOATS,
                "groupnorm_static: the call needs more scratch than is built in");
-  int dev = -1;
-  SDMI_CHECK_HIP(hipGetDevice(&dev));
-  SDMI_REQUIRE(dev >= 0 && dev < GN_MAX_DEVICES, "groupnorm_static: device ordinal %d not supported", dev);
-  float* ptr;
-  {
-    std::lock_guard<std::mutex> lock(g_gn_static_mu);
-    if (!g_gn_static_ptr[dev]) {
-      void* sym = nullptr;
-      SDMI_CHECK_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)));     // this device's copy of the array
-      SDMI_REQUIRE(sym != nullptr, "groupnorm_static: the scratch symbol has no address on device %d", dev);
-      g_gn_static_ptr[dev] = (float*)sym;
-    }
-    ptr = g_gn_static_ptr[dev];
-  }
+  float* ptr = nullptr;
+  SDMI_TRY(groupnorm_static_init(&ptr));
   GroupNormArgs a = a_in;
   a.scratch = ptr;      // every partial sum the second launch reads is written by the first: nothing to clear
   return groupnorm(a, stream);

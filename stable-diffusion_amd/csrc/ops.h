@@ -88,6 +88,7 @@ size_t groupnorm_scratch_floats(int B, int HW, int groups);
 int groupnorm(const GroupNormArgs& a, hipStream_t stream);
 // same, with the library's built-in per-GPU scratch (a.scratch is ignored); allocates nothing
 int groupnorm_static(const GroupNormArgs& a, hipStream_t stream);
+int groupnorm_static_init(float** out = nullptr);      // resolves the built-in scratch of the current device (not under capture)
 
 int layernorm(const void* x, void* out, const float* gamma, const float* beta, int rows, int d,
               float eps, int dtype, hipStream_t stream);
@@ -154,6 +155,7 @@ int ddpm_step(const float* x, const float* eps, float c_recip, float c_recipm1, 
               float noise_coef, const float* noise, float temperature, float* x_prev, float* pred_x0, int64_t n,
               hipStream_t s);
 // out = ca * a + cb * b   (stochastic_encode / q_sample with per-call scalars; fp32)
+int cfg_combine(const float* eps, float scale, float* out, int64_t n, hipStream_t s);
 int axpby(const float* a, const float* b, float ca, float cb, float* out, int64_t n, hipStream_t s);
 // known-region blend of the DDIM loop (fp32): out = (ca x0 + cb noise) * mask + (1 - mask) * img; mask has 1 or C channels
 int q_sample_blend(const float* x0, const float* noise, const float* mask, const float* img, float ca, float cb,

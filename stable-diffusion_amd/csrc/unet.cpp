@@ -129,6 +129,7 @@ struct sdmi_unet {
   GraphKey gseen; bool gseen_have = false;   // key of the last eager forward: a graph is recorded on its second sighting
   hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
   hipStream_t cap_stream = nullptr;      // capture happens here; replay goes to the caller's stream
+  int graph_nodes = 0;                   // kernel launches of the recorded forward
 
   ~sdmi_unet() {
     drop_graph();
@@ -138,7 +139,7 @@ struct sdmi_unet {
   void drop_graph() {
     if (gexec) (void)hipGraphExecDestroy(gexec);
     if (graph) (void)hipGraphDestroy(graph);
-    gexec = nullptr; graph = nullptr; ghave = false;
+    gexec = nullptr; graph = nullptr; ghave = false; graph_nodes = 0;
   }
 
   // ---- structure -----------------------------------------------------------------------------
@@ -292,6 +293,7 @@ struct sdmi_unet {
     SDMI_TRY(conv_gemm_init());
     SDMI_TRY(elementwise_init());
     SDMI_TRY(attention_init());
+    SDMI_TRY(groupnorm_static_init());
     std::vector<std::string> packed_keys;
     {
       const char* e = getenv("SDMI_LN_FOLD");
@@ -810,6 +812,11 @@ struct sdmi_unet {
       if (e != hipSuccess) { sdmi_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return SDMI_EHIP; }
       graph = g;
       SDMI_CHECK_HIP(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+      {
+        size_t n = 0;
+        SDMI_CHECK_HIP(hipGraphGetNodes(graph, nullptr, &n));
+        graph_nodes = (int)n;
+      }
       gkey = k; ghave = true;
     }
     SDMI_CHECK_HIP(hipGraphLaunch(gexec, f.s));
@@ -900,6 +907,8 @@ int sdmi_unet_set_cfg_duplicate(sdmi_unet* u, int enable) {
   u->cfg_dup = enable ? 1 : 0;
   return SDMI_OK;
 }
+
+int sdmi_unet_graph_launches(const sdmi_unet* u) { return u ? u->graph_nodes : 0; }
 
 int sdmi_unet_set_graph_mode(sdmi_unet* u, int enable) {
   SDMI_REQUIRE(u, "set_graph_mode: null handle");

@@ -149,6 +149,7 @@ struct VaeNet {
     if (finalized) { sdmi_set_error("finalize: already finalized"); return SDMI_ESTATE; }
     SDMI_TRY(store.check_complete(specs));
     SDMI_TRY(conv_gemm_init());
+    SDMI_TRY(groupnorm_static_init());
     SDMI_TRY(elementwise_init());
     std::vector<std::string> drop;
     auto P = [&](PackedConv* pc, const std::string& prefix, int cout, int cin, int taps) {

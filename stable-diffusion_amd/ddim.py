@@ -147,6 +147,7 @@ class DDIMSampler(object):
             pred_x0 = st.step(cond, int(step), index, use_original_steps=ddim_use_original_steps,
                               quantize_denoised=quantize_denoised, temperature=temperature,
                               noise_dropout=noise_dropout, score_corrector=score_corrector,
+                              corrector_kwargs=corrector_kwargs,
                               unconditional_guidance_scale=unconditional_guidance_scale, noise_fn=noise_fn,
                               want_pred_x0=img_callback is not None)
             if callback:
@@ -192,33 +193,54 @@ class DDIMSampler(object):
             self.x_in.view(-1, self.b, *self.x_in.shape[1:])[:] = x
 
         def step(self, cond, t_value, index, use_original_steps=False, quantize_denoised=False, temperature=1.,
-                 noise_dropout=0., score_corrector=None, unconditional_guidance_scale=1., noise_fn=None,
-                 want_pred_x0=True):
+                 noise_dropout=0., score_corrector=None, corrector_kwargs=None, unconditional_guidance_scale=1.,
+                 noise_fn=None, want_pred_x0=True):
+            """One p_sample_ddim (:5338-5375).  ``t_value`` is the step's timestep for the whole batch (what the
+            sampling loops pass, :5314) or a (b,) tensor of per-sample timesteps."""
             s = self.s
-            if quantize_denoised or score_corrector is not None or noise_dropout > 0.:
-                raise NotImplementedError("quantize_denoised / score_corrector / noise_dropout are not on the "
-                                          "MI355X sampling path (no reference script uses them)")
-            if self.t_val != t_value:
+            if quantize_denoised:
+                raise NotImplementedError("quantize_denoised needs a VQ first stage, which is not on the MI355X "
+                                          "sampling path (SD v1 uses the KL autoencoder)")
+            uniform = not torch.is_tensor(t_value)
+            if not uniform:
+                # t_in = cat([t] * 2) (:5345); the UNet then embeds every row's own timestep
+                self.t_in.view(-1, self.b)[:] = t_value.to(self.t_in.device, torch.int64).reshape(-1)
+                self.t_val = None
+            elif self.t_val != t_value:
                 self.t_in.fill_(t_value)
                 self.t_val = t_value
-            # t_in holds one value for every sample (the loop's torch.full((b,), step), :5308): the UNet may
-            # run its time-embedding MLP on a single row
+            # one value for every sample: the UNet may run its time-embedding MLP on a single row
             unet = s.model.model.diffusion_model
-            unet.set_uniform_timesteps(True)
+            unet.set_uniform_timesteps(uniform)
             unet.set_cfg_duplicate(self.doubled)       # x_in = cat([x] * 2): halves differ only in context
             try:
                 s.model.apply_model(self.x_in, self.t_in, cond, out=self.eps)
             finally:
                 unet.set_uniform_timesteps(False)
                 unet.set_cfg_duplicate(False)
+            eps, combine = self.eps, self.doubled
+            if score_corrector is not None:
+                # the corrector sees the guided score (:5347, :5351-5353): combine first, update without guidance
+                assert s.model.parameterization == "eps"
+                if self.doubled:
+                    eps = ops.cfg_combine(self.eps, unconditional_guidance_scale)
+                eps = score_corrector.modify_score(s.model, eps, self.x(), self.t_in[:self.b], cond,
+                                                   **(corrector_kwargs or {}))
+                eps = eps.to(self.x_next.device, torch.float32).contiguous()
+                combine = False
             a_t, a_prev, sigma_t, sqrt_1m = s._scalars(index, use_original_steps)
             noise = None
             if sigma_t != 0.:
                 shape = self.x_next.shape
                 noise = noise_fn(shape) if noise_fn is not None else torch.randn(shape, device=self.x_next.device)
                 noise = noise.to(self.x_next.device, torch.float32).contiguous()
+                if noise_dropout > 0.:
+                    # dropout(sigma * noise * temperature) (:5371-5373): the mask and its 1 / (1 - p) act on the noise
+                    # term, whose other factors are scalars
+                    noise = torch.nn.functional.dropout(noise * temperature, p=noise_dropout)
+                    temperature = 1.
             from ._lib import lib, check, ptr, stream_ptr
-            check(lib().sdmi_ddim_step(ptr(self.x_in), ptr(self.eps), 1 if self.doubled else 0,
+            check(lib().sdmi_ddim_step(ptr(self.x_in), ptr(eps), 1 if combine else 0,
                                        float(unconditional_guidance_scale), a_t, a_prev, sigma_t, sqrt_1m, ptr(noise),
                                        float(temperature), ptr(self.x_next), ptr(self.pred) if want_pred_x0 else None,
                                        self.x_next.numel(), stream_ptr()), "ddim_step")
@@ -244,15 +266,13 @@ class DDIMSampler(object):
         doubled = bool(unconditional_conditioning) and unconditional_guidance_scale != 1.
         st = self._StepState(self, x, doubled)
         t = torch.as_tensor(t).reshape(-1)
-        t_value = int(t[0])
-        # the fused step feeds one timestep to the whole batch (what the sampling loops pass, :5314); per-sample
-        # timesteps would silently all become t[0]
-        if not bool((t == t_value).all()):
-            raise NotImplementedError("p_sample_ddim: per-sample timesteps are not on the MI355X sampling path "
-                                      "(the DDIM loops use one timestep per step); got " + str(t.tolist()))
+        # one timestep for the batch (what the sampling loops pass, :5314) takes the single-row time embedding;
+        # per-sample timesteps go to the UNet as they are (:5344-5346)
+        t_value = int(t[0]) if bool((t == t[0]).all()) else t
         pred = st.step(c, t_value, index, use_original_steps=use_original_steps,
                        quantize_denoised=quantize_denoised, temperature=temperature, noise_dropout=noise_dropout,
-                       score_corrector=score_corrector, unconditional_guidance_scale=unconditional_guidance_scale,
+                       score_corrector=score_corrector, corrector_kwargs=corrector_kwargs,
+                       unconditional_guidance_scale=unconditional_guidance_scale,
                        noise_fn=(lambda shape: noise) if noise is not None else None)
         return st.x().clone(), pred.clone()
 

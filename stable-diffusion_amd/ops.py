@@ -209,6 +209,15 @@ def ddpm_step(x, eps, sqrt_recip_acp, sqrt_recipm1_acp, coef1, coef2, noise_coef
     return x_prev, pred
 
 
+def cfg_combine(eps2, scale, out=None):
+    """e_uncond + scale * (e_cond - e_uncond) for eps2 = cat([e_uncond, e_cond]) on the batch axis."""
+    eps2 = _f32(eps2)
+    b = eps2.shape[0] // 2
+    out = torch.empty_like(eps2[:b]) if out is None else _f32(out)
+    check(_lib.lib().sdmi_cfg_combine(ptr(eps2), float(scale), ptr(out), out.numel(), stream_ptr()), "cfg_combine")
+    return out
+
+
 def axpby(a, b, ca, cb, out=None):
     a, b = _f32(a), _f32(b)
     out = torch.empty_like(a) if out is None else _f32(out)

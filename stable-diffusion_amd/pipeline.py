@@ -62,10 +62,12 @@ def initial_latents(batch, h, w, device="cuda", first_sample=0, seed=42):
 
 
 @torch.no_grad()
-def txt2img(model, x_T, uc, c, steps=50, scale=7.5, eta=0.0, sampler=None):
+def txt2img(model, x_T, uc, c, steps=50, scale=7.5, eta=0.0, sampler=None, as_uint8=False):
     """One batch through the whole path; returns images (B,3,8h,8w) in [0,1] and the final latents.
     ``uc`` / ``c`` are conditioning tensors (B,77,768), or token ids / text for the model's text transformer
-    (txt2img.py:285-290: get_learned_conditioning of the empty prompt and of the prompts)."""
+    (txt2img.py:285-290: get_learned_conditioning of the empty prompt and of the prompts).  ``as_uint8``: the
+    images come back as the (B,8h,8w,3) uint8 array the script hands to Image.fromarray (txt2img.py:307-317), a
+    quarter of the bytes for a multi-GPU gather."""
     from . import ops
     from .ddim import DDIMSampler
     sampler = sampler or DDIMSampler(model)
@@ -78,7 +80,8 @@ def txt2img(model, x_T, uc, c, steps=50, scale=7.5, eta=0.0, sampler=None):
                           unconditional_guidance_scale=scale,
                           unconditional_conditioning=True if scale != 1.0 else None, eta=eta, x_T=x_T,
                           verbose=False)
-    img = ops.to_image(model.decode_first_stage(z))
+    dec = model.decode_first_stage(z)
+    img = ops.to_image_u8(dec) if as_uint8 else ops.to_image(dec)
     return img, z
 
 

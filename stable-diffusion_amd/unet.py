@@ -146,6 +146,10 @@ class UNetModel:
     def set_graph_mode(self, enable: bool):
         check(_lib.lib().sdmi_unet_set_graph_mode(self._h, 1 if enable else 0), "set_graph_mode")
 
+    def graph_launches(self):
+        """Kernel launches of the forward graph currently recorded (0 if the last forward ran eagerly)."""
+        return int(_lib.lib().sdmi_unet_graph_launches(self._h))
+
     def device_bytes(self):
         return int(_lib.lib().sdmi_unet_device_bytes(self._h))
 

@@ -19,10 +19,31 @@ def golden(name):
     return {k: (str(z[k]) if z[k].dtype.kind in "US" else torch.from_numpy(np.asarray(z[k]))) for k in z.files}
 
 
-def max_rel_err(a, b):
-    """max |a-b| / max |b|  -- the per-call error measure used for the UNet parity bar."""
+def rel_l2(a, b):
+    """||a-b||_2 / ||b||_2."""
     a, b = a.double(), b.double()
-    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def worst_elem_err(a, b, floor=1e-2):
+    """max over elements of |a-b| / max(|b|, floor * max|b|): the element-wise relative error, with the
+    denominator floored at 1 % of the largest reference magnitude so that near-zero entries do not divide by ~0.
+    A localised error in a low-magnitude region shows up here up to 100 x larger than in max_rel_err."""
+    a, b = a.double(), b.double()
+    den = b.abs().clamp_min(floor * float(b.abs().max().clamp_min(1e-30)))
+    return float(((a - b).abs() / den).max())
+
+
+def max_rel_err(a, b):
+    """max |a-b| / max |b|  -- the per-call error measure used for the UNet parity bar (one global normaliser).
+    Every call also prints the two stricter companions, relative L2 and the worst element-wise error, so a test
+    log shows all three (`pytest -s`, or the captured output of a failure)."""
+    a, b = a.double(), b.double()
+    e = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    if a.numel() > 1:
+        print(f"  [parity] max|a-b|/max|b| {e:.3e}   rel-L2 {rel_l2(a, b):.3e}   worst element-wise "
+              f"(floor 1% of max|b|) {worst_elem_err(a, b):.3e}   n={a.numel()}")
+    return e
 
 
 def psnr(a, b, peak=1.0):

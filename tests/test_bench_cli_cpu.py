@@ -20,7 +20,7 @@ def test_bench_rejects_a_world_size_that_contradicts_gpus():
 
 def test_bench_gpus_flag_needs_that_many_devices():
     """Outside torchrun `--gpus N` starts N ranks itself; with fewer visible devices it says so instead of
-    starting ranks that would fail one by one (device counting does not initialise the GPU)."""
+    starting ranks that would fail one by one (devices are counted from sysfs and the environment, with no HIP call)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SDMI_BENCH_SHARE_DEVICE")}
     env["HIP_VISIBLE_DEVICES"] = ""
     res = _run(["--gpus", "64", "--steps", "1"], env)

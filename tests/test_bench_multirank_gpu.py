@@ -37,6 +37,11 @@ def test_bench_two_ranks_one_device():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 4
     assert out["value"] > 0 and out["steps"] == 1 and out["warmup"] == 1
     assert "roofline" in out and out["unit"] == "images/sec"
+    # what lets a scaling record prove that the gather really spanned the ranks: backend and rank count as the
+    # process group reports them, the per-rank payload (2 uint8 images of 256x256x3) and the gather's own time
+    col = out["collective"]
+    assert col["backend"] == "gloo" and col["ranks"] == 2 and col["bytes_per_rank"] == 2 * 256 * 256 * 3
+    assert col["ms"] > 0
 
 
 def test_bench_gpus_flag_starts_the_ranks_and_fixed_list_mode():
@@ -50,3 +55,4 @@ def test_bench_gpus_flag_starts_the_ranks_and_fixed_list_mode():
     out = _one_json_line(res, only=True)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["global_batch"] == 6
     assert out["value"] > 0 and abs(out["value"] - 6 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    assert out["collective"]["ranks"] == 2 and out["collective"]["bytes_per_rank"] == 3 * 256 * 256 * 3

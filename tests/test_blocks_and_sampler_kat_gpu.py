@@ -131,6 +131,36 @@ def test_layernorm_row_sums_from_the_producing_gemm(dt, monkeypatch):
     del nets
 
 
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_layernorm_row_sums_with_a_large_common_offset(dt, monkeypatch):
+    """The row sums the producing GEMM leaves are plain (sum, sum of squares) in fp32, so the variance is a
+    difference of two large numbers when a row sits far from zero.  Rows of mean ~50 and spread ~0.6 (proj_in's
+    bias raised by 50: outlier channels of real checkpoints look like this) must still give the result of the
+    separate statistics kernel, which shifts the data first."""
+    sdmi = importlib.import_module("stable-diffusion_amd")
+    cfg = S.sd_v1_unet_config(4)
+    nets = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SDMI_LN_PRODUCER_STATS", flag)
+        net = sdmi.UNetModel(**cfg, compute_dtype=dt)
+        sd = synth.synth_state_dict(net.state_dict_shapes(), 0, device="cuda")
+        for name in ("input_blocks.1.1", "middle_block.1"):
+            sd[name + ".proj_in.bias"] = sd[name + ".proj_in.bias"] + 50.0
+        net.load_state_dict(sd)
+        nets.append(net)
+    ctx = g2_u("ctx", (2, 77, 768)).cuda()
+    for name, hw, ch in (("input_blocks.1.1", 64, 320), ("middle_block.1", 8, 1280)):
+        idx = _block_index(nets[0], "st", name)
+        x = nhwc(synth.normal(5, f"ps.{name}", (2, ch, hw, hw)), dt)
+        ya = nets[0].run_block("st", idx, x, context=ctx)
+        yb = nets[1].run_block("st", idx, x, context=ctx)
+        torch.cuda.synchronize()
+        err = max_rel_err(ya.float().cpu(), yb.float().cpu())
+        print(f"row sums with offset {dt} {name} {hw}x{hw}: {err:.3e}")
+        assert err < TOL[dt]
+    del nets
+
+
 def test_q_sample_and_stochastic_encode_g5_bit_exact():
     """LatentDiffusion.q_sample (:3892-3895) with per-sample timesteps and DDIMSampler.stochastic_encode
     (:5378-5391), both with a timestep per sample and with the one-element tensor of inpaint_with_text.py:260."""
@@ -187,14 +217,97 @@ def test_g13_sample_with_known_region(dt):
     assert err < (5e-4 if dt == "fp32" else 5e-2)
 
 
-def test_p_sample_ddim_refuses_per_sample_timesteps():
+def _oracle_unet_sd():
+    from oracle import unet_ref
+    st = S.unet_structure(**S.sd_v1_unet_config(4))
+    return unet_ref, st, synth.synth_state_dict(S.unet_param_shapes(st), 0)
+
+
+def test_p_sample_ddim_per_sample_timesteps_against_oracle():
+    """p_sample_ddim honours a timestep per sample (:5344-5346: t_in = cat([t] * 2) goes to the model, the update's
+    scalars come from `index`): fp32 mode against the oracle's UNet + guidance combine + update, <= 1e-4; a batch
+    whose timesteps are all equal takes the single-row embedding path and must agree with the per-row path."""
+    from oracle import sampler_ref
+    unet_ref, st, sd = _oracle_unet_sd()
     model = device_latent_diffusion(4, "crossattn", "fp32")
     sampler = importlib.import_module("stable-diffusion_amd").DDIMSampler(model)
     sampler.make_schedule(50, ddim_eta=0.0, verbose=False)
-    x = torch.zeros(2, 4, 16, 16, device="cuda")
-    ctx = torch.zeros(2, 77, 768, device="cuda")
-    with pytest.raises(NotImplementedError, match="per-sample timesteps"):
-        sampler.p_sample_ddim(x, ctx, torch.tensor([981, 961]), 49)
+    x = synth.normal(11, "psd.x", (2, 4, 16, 16))
+    ctx = torch.cat([synth.normal(2, "psd.uc", (2, 77, 768)), synth.normal(1, "psd.c", (2, 77, 768))])
+    t = torch.tensor([981, 961])
+    index = 49
+    x_prev, pred = sampler.p_sample_ddim(x.cuda(), ctx.cuda(), t.cuda(), index, unconditional_guidance_scale=7.5,
+                                         unconditional_conditioning=True)
+    torch.cuda.synchronize()
+    eps = unet_ref.unet_forward(sd, st, torch.cat([x] * 2), torch.cat([t] * 2), ctx)
+    e_u, e_c = eps.chunk(2)
+    tab = sampler_ref.ddim_tables(sampler_ref.ddpm_tables()["alphas_cumprod"], 50, 0.0)
+    xp_ref, p0_ref = sampler_ref.ddim_update(x, sampler_ref.cfg_combine(e_u, e_c, 7.5), tab["alphas"][index],
+                                             tab["alphas_prev"][index], tab["sigmas"][index],
+                                             tab["sqrt_one_minus_alphas"][index], torch.zeros_like(x))
+    ex, ep = max_rel_err(x_prev.cpu(), xp_ref), max_rel_err(pred.cpu(), p0_ref)
+    print(f"p_sample_ddim per-sample t: x_prev {ex:.3e} pred_x0 {ep:.3e}")
+    assert ex < 1e-4 and ep < 1e-4
+    # equal timesteps: the uniform-timestep shortcut and the per-row embedding agree
+    st_a = sampler._StepState(sampler, x.cuda(), True)
+    st_a.step(ctx.cuda(), 981, index, unconditional_guidance_scale=7.5)
+    st_b = sampler._StepState(sampler, x.cuda(), True)
+    st_b.step(ctx.cuda(), torch.tensor([981, 981]), index, unconditional_guidance_scale=7.5)
+    assert max_rel_err(st_a.x().cpu(), st_b.x().cpu()) < 1e-5
+
+
+def test_ddim_score_corrector_and_noise_dropout():
+    """The two side branches of p_sample_ddim: `score_corrector.modify_score` receives the guided score and what it
+    returns drives the update (:5351-5353), checked against the oracle's update on the corrected score; and
+    `noise_dropout` (:5372-5373) zeroes a share of the noise term and scales the rest by 1 / (1 - p)."""
+    from oracle import sampler_ref
+    ops = importlib.import_module("stable-diffusion_amd.ops")
+    model = device_latent_diffusion(4, "crossattn", "fp32")
+    sampler = importlib.import_module("stable-diffusion_amd").DDIMSampler(model)
+    sampler.make_schedule(50, ddim_eta=0.5, verbose=False)
+    x = synth.normal(11, "psd.x", (2, 4, 16, 16)).cuda()
+    ctx = torch.cat([synth.normal(2, "psd.uc", (2, 77, 768)), synth.normal(1, "psd.c", (2, 77, 768))]).cuda()
+    t = torch.tensor([981, 981]).cuda()
+    index = 49
+    seen = {}
+
+    class Corrector:
+        def modify_score(self, mdl, e_t, xx, tt, c, gain=1.0):
+            seen.update(e=e_t.clone(), x=xx.clone(), t=tt.clone(), gain=gain, model=mdl)
+            return gain * e_t + 0.25 * xx
+
+    noise = synth.normal(12, "psd.noise", (2, 4, 16, 16)).cuda()
+    x_prev, pred = sampler.p_sample_ddim(x, ctx, t, index, unconditional_guidance_scale=7.5,
+                                         unconditional_conditioning=True, score_corrector=Corrector(),
+                                         corrector_kwargs={"gain": 0.5}, noise=noise)
+    torch.cuda.synchronize()
+    assert seen["model"] is model and seen["gain"] == 0.5
+    assert torch.equal(seen["x"], x) and torch.equal(seen["t"], t)
+    # the score handed over is the guided one: the combine kernel on the UNet's output for the doubled batch
+    # (the sampler's call runs with its uniform-timestep / duplicated-pair promises on, which may pick other GEMM
+    # plans than this plain call: equal within the fp32 bar, while the combine kernel itself is bit-exact)
+    eps2 = model.apply_model(torch.cat([x] * 2), torch.cat([t] * 2), ctx)
+    e_u, e_c = eps2.cpu().chunk(2)
+    assert torch.equal(ops.cfg_combine(eps2, 7.5).cpu(), sampler_ref.cfg_combine(e_u, e_c, 7.5))
+    assert max_rel_err(seen["e"].cpu(), sampler_ref.cfg_combine(e_u, e_c, 7.5)) < 1e-4
+    tab = sampler_ref.ddim_tables(sampler_ref.ddpm_tables()["alphas_cumprod"], 50, 0.5)
+    e_mod = 0.5 * seen["e"].cpu() + 0.25 * x.cpu()
+    xp_ref, p0_ref = sampler_ref.ddim_update(x.cpu(), e_mod, tab["alphas"][index], tab["alphas_prev"][index],
+                                             tab["sigmas"][index], tab["sqrt_one_minus_alphas"][index], noise.cpu())
+    assert torch.equal(x_prev.cpu(), xp_ref) and torch.equal(pred.cpu(), p0_ref)
+    # noise dropout: with p = 0.5 every element's noise term is either absent or doubled
+    st = sampler._StepState(sampler, x, True)
+    st.step(ctx, 981, index, unconditional_guidance_scale=7.5, noise_fn=lambda shape: noise, noise_dropout=0.5)
+    st0 = sampler._StepState(sampler, x, True)
+    st0.step(ctx, 981, index, unconditional_guidance_scale=7.5, noise_fn=lambda shape: torch.zeros_like(noise))
+    term = (st.x() - st0.x()).cpu()
+    full = float(tab["sigmas"][index]) * noise.cpu()
+    dropped = term.abs() < 1e-6
+    doubled = (term - 2.0 * full).abs() < 1e-4 * full.abs().max()
+    assert bool((dropped | doubled).all())
+    assert 0.3 < float(dropped.float().mean()) < 0.7
+    with pytest.raises(NotImplementedError, match="VQ first stage"):
+        sampler.p_sample_ddim(x, ctx, t, index, quantize_denoised=True)
 
 
 def test_default_compute_dtype_follows_use_fp16():

@@ -450,6 +450,14 @@ def test_small_linear(ops):
     ref = F.linear(x, w[:, :64].contiguous(), None)
     y = ops.small_linear(x.cuda(), w[:, :64].contiguous().cuda()).cpu()
     assert max_rel_err(y, ref) < 2e-6
+    # two rows of a long x (96 KiB parked in LDS, beyond the default dynamic limit) on the narrow-output path
+    x = rnd("sl.x3", (2, 12288))
+    w3 = rnd("sl.w3", (256, 12288), -0.02, 0.02)
+    ref = F.linear(x, w3, None)
+    y = ops.small_linear(x.cuda(), w3.cuda()).cpu()
+    assert max_rel_err(y, ref) < 1e-5
+    y1 = ops.small_linear(x[:1].contiguous().cuda(), w3.cuda()).cpu()
+    assert max_rel_err(y1, ref[:1]) < 1e-5
 
 
 def test_ddim_step_g5_bit_exact(ops):

@@ -116,6 +116,35 @@ def test_g7_c3_50_step_trajectory_psnr_fp16():
     assert p >= 35.0
 
 
+def test_c3_batch8_50_steps_graph_replay_against_golden():
+    """The exact sequence bench.py times (txt2img.py:278-308 at batch 8: UNet batch 16 with the sampler's
+    uniform-timestep and duplicated-pair promises, 50 DDIM steps as a replayed launch graph, CFG 7.5, VAE decode,
+    clamp) held against the reference: slots 0 and 5 of the batch carry the x_T and conditioning of the reference's
+    own 50-step trajectory, the other six are unrelated samples.  Image PSNR >= 35 dB against the reference's image,
+    and the two slots must agree bit for bit (no cross-sample term, no slot-dependent arithmetic)."""
+    pipeline = importlib.import_module("stable-diffusion_amd.pipeline")
+    model = device_latent_diffusion(4, "crossattn", "fp16")
+    unet = model.model.diffusion_model
+    g = golden("g7_c3_traj")
+    sampler = sampler_for(model)
+    x_T = pipeline.initial_latents(8, 64, 64).clone()
+    uc, c = pipeline.synthetic_conditioning(8)
+    uc, c = uc.clone(), c.clone()
+    for slot in (0, 5):
+        x_T[slot], uc[slot], c[slot] = g["x_T"][0].cuda(), g["uc"][0].float().cuda(), g["c"][0].float().cuda()
+    img, z = pipeline.txt2img(model, x_T, uc, c, steps=50, scale=7.5, sampler=sampler)
+    torch.cuda.synchronize()
+    assert unet.graph_launches() > 0, "the loop did not run as a replayed graph"
+    assert tuple(img.shape) == (8, 3, 512, 512)
+    p = psnr(img[0].cpu(), g["image"].float()[0])
+    err = max_rel_err(z[0].cpu(), g["z"][0])
+    print(f"C3 batch 8, 50 steps, graph replay ({unet.graph_launches()} launches per forward): slot 0 latent err "
+          f"{err:.3e}, image PSNR {p:.1f} dB")
+    assert p >= 35.0
+    assert torch.equal(z[0], z[5]) and torch.equal(img[0], img[5])
+    assert not torch.equal(z[0], z[1])
+
+
 def test_full_size_vae_decode_batch8_against_golden():
     """The benchmark's decode shape (8 latents of 64x64 -> 8 images of 512x512): the reference's final latent of
     the 50-step trajectory, eight times; every decoded copy must match the reference's image (stored as fp16) and

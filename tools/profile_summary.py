@@ -37,28 +37,72 @@ if stats:
 
 
 def per_launch(dirname, counter):
+    """Values of `counter` for the dominant kernel's dispatches, in dispatch order."""
     vals = []
     for f in glob.glob(os.path.join(ROOT, "gpurun_out", dirname, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if DOM in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                vals.append(float(r["Counter_Value"]))
+                vals.append((int(r["Dispatch_Id"]), float(r["Counter_Value"]),
+                             (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    vals.sort()
     return vals
+
+
+def dominant_labels():
+    """Shape labels of the dominant kernel's launches in launch order (bench.py with SDMI_BENCH_LABELS)."""
+    path = os.path.join(ROOT, "gpurun_out", "pmc_labels.csv")
+    if not os.path.exists(path):
+        return []
+    out = []
+    with open(path) as f:
+        next(f)
+        for line in f:
+            cls, label = line.split(",")[:2]
+            if cls == "conv_gemm" and label.endswith(" k1"):
+                out.append("conv3x3" if " t9 " in label else "pointwise")
+    return out
 
 
 fetch, write = per_launch("pmc_fetch", "FETCH_SIZE"), per_launch("pmc_write", "WRITE_SIZE")
 if fetch and write:
     # rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes: doubled
-    fetch_b = 2.0 * 1024.0 * sum(fetch) / len(fetch)
-    write_b = 1024.0 * sum(write) / len(write)
+    mean_v = lambda rows: sum(r[1] for r in rows) / len(rows)
+    fetch_b = 2.0 * 1024.0 * mean_v(fetch)
+    write_b = 1024.0 * mean_v(write)
+    doc = {"kernel": "conv_gemm_pp_kernel<half, PPShape<10,2,2>>", "launches_fetch_pass": len(fetch),
+           "launches_write_pass": len(write), "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
+           "hbm_bytes_per_launch": fetch_b + write_b,
+           "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+                     "bench.py --no-c2 --no-cpu-baseline --no-roofline --no-graph --steps 1 --warmup 0 "
+                     "--ddim-steps 4; KiB -> bytes; FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B); "
+                     "classes: the i-th dispatch of the kernel is the i-th launch label of the same command "
+                     "(taps = 9: conv3x3, taps = 1: pointwise)"}
+    labels = dominant_labels()
+    if len(labels) == len(fetch) == len(write):
+        doc["classes"] = {}
+        for name in ("conv3x3", "pointwise"):
+            fr = [r for r, l in zip(fetch, labels) if l == name]
+            wr = [r for r, l in zip(write, labels) if l == name]
+            if not fr:
+                continue
+            fb, wb = 2.0 * 1024.0 * mean_v(fr), 1024.0 * mean_v(wr)
+            doc["classes"][name] = {"launches": len(fr), "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+                                    "hbm_bytes_per_launch": fb + wb,
+                                    "avg_duration_us": sum(r[2] for r in fr + wr) / (len(fr) + len(wr))}
+    else:
+        print(f"labels ({len(labels)}) do not line up with the dispatches ({len(fetch)}, {len(write)}): no classes")
+    # sustained clock per class from the SQ pass, joined the same way
+    sqb = per_launch("pmc_sq", "SQ_BUSY_CYCLES")
+    if "classes" in doc and len(sqb) == len(labels):
+        for name, c in doc["classes"].items():
+            rows = [r for r, l in zip(sqb, labels) if l == name]
+            c["shader_clock_GHz"] = sum(r[1] for r in rows) / 32.0 / sum(r[2] for r in rows) / 1e3
     out = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
-    json.dump({"kernel": "conv_gemm_pp_kernel<half, PPShape<10,2,2>>", "launches_fetch_pass": len(fetch),
-               "launches_write_pass": len(write), "fetch_bytes_per_launch": fetch_b, "write_bytes_per_launch": write_b,
-               "hbm_bytes_per_launch": fetch_b + write_b,
-               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-                         "bench.py --no-c2 --no-cpu-baseline --no-roofline --no-graph --steps 1 --warmup 0 "
-                         "--ddim-steps 4; KiB -> bytes; FETCH_SIZE doubled (gfx950 tallies 128-B requests as 64 B)"},
-              open(out, "w"), indent=1)
+    json.dump(doc, open(out, "w"), indent=1)
     print("wrote", out, f"fetch {fetch_b / 1e6:.1f} MB + write {write_b / 1e6:.1f} MB per launch")
+    for name, c in doc.get("classes", {}).items():
+        print(f"  {name}: {c['launches']} launches, {c['hbm_bytes_per_launch'] / 1e6:.1f} MB per launch, "
+              f"{c['avg_duration_us']:.1f} us, clock {c.get('shader_clock_GHz', 0):.2f} GHz")
 
 
 # ---- per kernel class: SQ issue/busy counters and HBM traffic of the normalisation kernels -----------------
@@ -71,6 +115,8 @@ def classify(k):
         return "conv_gemm 128x128"
     if "attn_flash" in k:
         return "attn_flash"
+    if "cross_attn" in k:
+        return "cross_attn"
     if "gn_partial" in k:
         return "gn_partial"
     if "gn_apply" in k:

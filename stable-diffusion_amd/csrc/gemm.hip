@@ -65,6 +65,10 @@ struct GemmParams {
   float ln_inv_d, ln_eps;  //    row, as a producing GEMM left them (row length 1 / ln_inv_d)
   float2* rs_out;          // this launch leaves row sums of its OUTPUT for a LayerNorm behind it: rs_parts pairs
   int rs_parts;            //    (sum, sum of squares of the stored values) per row; null = none
+  int w_rows;              // > 0: one weight matrix per sample, rows m belong to sample m / w_rows (a tile never
+  size_t w_stride;         //    straddles two samples: the launcher picks BM | w_rows); bytes between the matrices
+  int vec_stride;          //    floats between the samples' bias / ln_colsum vectors (0: one vector for all)
+  int softmax_seg;         // 1: every 80-column segment of an output row is replaced by its softmax (base 2)
 };
 
 // (rstd, rstd * mean) of row m for a GEMM with a folded LayerNorm
@@ -571,6 +575,42 @@ typedef PPShape<5, 1, 3, 2> PP160H;     // 128x160: layers whose 256-row tiles w
 typedef PPShape<4, 1, 3> PP128;         // 256x128: 128-channel layers (the VAE decoder's 512x512 stage)
 typedef PPShape<5, 1, 3, 1> PP160Q;     // 64x160: small problems (UNet batch 2) whose 128-row tiles leave most CUs idle
 
+// Softmax (base 2: the scores arrive scaled by log2 e) over each 80-column segment of the wave's rows, in the
+// accumulators: acc[i][j] holds columns 16 i + 4 fq .. +3 of row (lane & 15) + 16 j, so a row's segment is five
+// fragments in the four lanes that differ in fq.  Cross-attention scores against a text context of up to 80
+// tokens, one segment per head; columns beyond the context carry a large negative bias and come out as zeros.
+template <int NFW, int MJ>
+__device__ __forceinline__ void softmax_seg80(f32x4 (&acc)[NFW][MJ]) {
+  static_assert(NFW % 5 == 0, "a wave must own whole 80-column segments");
+#pragma unroll
+  for (int sg = 0; sg < NFW / 5; ++sg)
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const f32x4 v = acc[5 * sg + i][j];
+        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        f32x4 v = acc[5 * sg + i][j];
+        v.x = __builtin_amdgcn_exp2f(v.x - mx); v.y = __builtin_amdgcn_exp2f(v.y - mx);
+        v.z = __builtin_amdgcn_exp2f(v.z - mx); v.w = __builtin_amdgcn_exp2f(v.w - mx);
+        sum += (v.x + v.y) + (v.z + v.w);
+        acc[5 * sg + i][j] = v;
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) acc[5 * sg + i][j] *= inv;
+    }
+}
+
 template <typename T, typename S, bool TI>
 __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit operands only");
@@ -593,6 +633,11 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   const int m0 = tile_m * S::BM, n0 = tile_n * S::BN;
   const int kt_begin = blockIdx.y * p.kt_per_split;
   const int nk = min(p.nkt, kt_begin + p.kt_per_split) - kt_begin;
+  // per-sample weights (and bias / column sums): this tile's sample
+  const int smp = p.w_rows > 0 ? __builtin_amdgcn_readfirstlane(m0 / p.w_rows) : 0;
+  const char* const wmat = p.w + (size_t)smp * p.w_stride;
+  const float* const biasv = p.bias ? p.bias + (size_t)smp * p.vec_stride : nullptr;
+  const float* const colsumv = p.ln_colsum ? p.ln_colsum + (size_t)smp * p.vec_stride : nullptr;
 
   // ---- loader state ----------------------------------------------------------------------------
   const int lrow = lane >> 3;
@@ -746,8 +791,8 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   auto prefetch_w = [&](int stage) {      // follows prefetch_a of the same tile (w_step)
     char* wbuf = smem + stage * S::STAGE_BYTES + S::A_BYTES + wp_first * 1024;
 #pragma unroll
-    for (int i = 0; i < S::WP_LO; ++i) glds16(p.w + i * wpitch8 + wofs, wbuf + i * 1024);
-    if (wp_extra) glds16(p.w + S::WP_LO * wpitch8 + wofs, wbuf + S::WP_LO * 1024);
+    for (int i = 0; i < S::WP_LO; ++i) glds16(wmat + i * wpitch8 + wofs, wbuf + i * 1024);
+    if (wp_extra) glds16(wmat + S::WP_LO * wpitch8 + wofs, wbuf + S::WP_LO * 1024);
     if constexpr (tapinner) wofs += w_step;
     else wofs += 128;
   };
@@ -794,9 +839,9 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
       }
 #pragma unroll
       for (int i = 0; i < NFW; ++i) {
-        const f32x4 c = *reinterpret_cast<const f32x4*>(p.ln_colsum + ncol + i * 16);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(colsumv + ncol + i * 16);
         f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) b = *reinterpret_cast<const f32x4*>(p.bias + ncol + i * 16);
+        if (biasv) b = *reinterpret_cast<const f32x4*>(biasv + ncol + i * 16);
 #pragma unroll
         for (int j = 0; j < MJ; ++j) acc[i][j] = b * inv[j] - mean[j] * c;
       }
@@ -804,7 +849,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
 #pragma unroll
       for (int i = 0; i < NFW; ++i) {
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (own_epilogue && p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + ncol + i * 16);
+        if (own_epilogue && biasv) bv = *reinterpret_cast<const f32x4*>(biasv + ncol + i * 16);
 #pragma unroll
         for (int j = 0; j < MJ; ++j) acc[i][j] = bv;
       }
@@ -930,6 +975,9 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
     for (int i = 0; i < NFW; ++i)
 #pragma unroll
       for (int j = 0; j < MJ; ++j) acc[i][j] *= ln_r[j];
+  }
+  if constexpr (NFW == 5) {       // (the 160-column shapes only: the launcher never sends score GEMMs elsewhere)
+    if (p.softmax_seg) softmax_seg80<NFW, MJ>(acc);
   }
   if (p.wide_store) {
     // all stage reads and DMAs are retired behind the last barrier: the stages are free
@@ -1206,7 +1254,37 @@ int small_splits(int M, int N, int nkt) {
   return s < 1 ? 1 : s;
 }
 
-Plan make_plan(int M, int N, int K, int dtype, bool geglu) {
+constexpr double kind_tk(int kind) {
+  return kind == KIND_PP320 ? T_KT_PP320_US : (kind == KIND_PP256 ? T_KT_PP256_US :
+         (kind == KIND_PP160 ? T_KT_PP160_US : (kind == KIND_PP128 ? T_KT_PP128_US :
+         (kind == KIND_PP160Q ? T_KT_PP160Q_US : T_KT_PP160H_US))));
+}
+
+// Launches with one weight matrix per sample (row_unit = rows per sample > 0): large-tile kernels whose row count
+// divides row_unit, no split-K; with `seg` (softmax over 80-column segments in the epilogue) only the 160-column
+// shapes, whose waves own exactly one segment.  kind = -1: no shape fits.
+Plan make_plan_per_sample(int M, int N, int K, int row_unit, bool seg) {
+  const int nkt = K / 64;
+  Plan best;
+  best.kind = -1; best.splits = 1;
+  double best_t = 0.0;
+  for (int kind = KIND_PP320; kind <= KIND_PP160Q; ++kind) {
+    const int bn = kind == KIND_PP320 ? 320 : (kind == KIND_PP256 ? 256 : (kind == KIND_PP128 ? 128 : 160));
+    const int bm = kind == KIND_PP160H ? 128 : (kind == KIND_PP160Q ? 64 : 256);
+    if (N % bn != 0 || row_unit % bm != 0 || M % bm != 0) continue;
+    if (seg && bn != 160) continue;
+    const long tiles = (long)(M / bm) * (N / bn);
+    const double t = (double)((tiles + 255) / 256) * (nkt + 3.0) * kind_tk(kind);
+    if (best.kind < 0 || t < best_t) { best.kind = kind; best_t = t; }
+  }
+  return best;
+}
+
+Plan make_plan(int M, int N, int K, int dtype, bool geglu, int row_unit = 0, bool seg = false) {
+  if (row_unit > 0) {
+    if (dtype == SDMI_F32 || geglu) { Plan none; none.kind = -1; none.splits = 1; return none; }
+    return make_plan_per_sample(M, N, K, row_unit, seg);
+  }
   const int BK = dtype == SDMI_F32 ? 32 : 64;
   const int nkt = K / BK;
   Plan best;
@@ -1268,15 +1346,17 @@ bool use_tap_inner(const GemmParams& p) {
 }
 
 // kernel for an explicit split count (callers size the slab with conv_gemm_pick_splits)
-int pick_kind(int M, int N, int K, int dtype, bool geglu) { return make_plan(M, N, K, dtype, geglu).kind; }
+int pick_kind(int M, int N, int K, int dtype, bool geglu, int row_unit = 0, bool seg = false) {
+  return make_plan(M, N, K, dtype, geglu, row_unit, seg).kind;
+}
 
 int kind_bn(int kind) {
   return kind == KIND_PP320 ? 320 : (kind == KIND_PP256 ? 256 : (kind == KIND_SMALL || kind == KIND_PP128 ? 128 : 160));
 }
 // pairs per row a launch with row_stats_out writes: the large-tile kernels leave one per (tile along N, wave
 // group) from their epilogue, everything else a single one
-int row_stat_parts(int M, int N, int K, int dtype, bool geglu, int splits) {
-  const int kind = pick_kind(M, N, K, dtype, geglu);
+int row_stat_parts(int M, int N, int K, int dtype, bool geglu, int splits, int row_unit = 0) {
+  const int kind = pick_kind(M, N, K, dtype, geglu, row_unit);
   if (kind == KIND_SMALL || splits > 1 || geglu || dtype == SDMI_F32) return 1;
   return 2 * (N / kind_bn(kind));
 }
@@ -1307,6 +1387,13 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   p.ln_nparts = a.ln_nparts; p.ln_eps = a.ln_eps;
   p.ln_inv_d = 1.0f / (float)(a.taps * (p.c0 + p.c1));
   p.rs_out = nullptr; p.rs_parts = 0;
+  p.w_rows = a.w_rows; p.w_stride = a.w_rows > 0 ? (size_t)a.N * a.taps * (a.c0 + (a.a1 ? a.c1 : 0)) * sizeof(T) : 0;
+  p.vec_stride = a.w_rows > 0 && a.vec_per_sample ? a.N : 0; p.softmax_seg = a.softmax_seg;
+  SDMI_REQUIRE(a.w_rows >= 0 && (a.w_rows == 0 || (a.taps == 1 && !a.a1 && !a.rowadd && !a.geglu && !a.out_f32 &&
+                                                   sizeof(T) == 2 && a.splits <= 1)),
+               "conv_gemm: per-sample weights need a single-source 16-bit token GEMM without rowadd / GEGLU / split-K");
+  SDMI_REQUIRE(!a.softmax_seg || (a.w_rows > 0 && a.N % 80 == 0 && !a.resid && !a.row_stats_out && !a.dup_rows),
+               "conv_gemm: the segment softmax belongs to per-sample score GEMMs (N a multiple of 80, plain store)");
   SDMI_REQUIRE(a.ln_nparts >= 0 && a.ln_nparts <= 16 && (a.ln_nparts == 1 || a.ln_nparts % 2 == 0),
                "conv_gemm: ln_nparts must be 0, 1 or an even number up to 16");
   SDMI_REQUIRE(!a.row_stats_out || (!a.geglu && !a.out_f32), "conv_gemm: row sums are not available with GEGLU / fp32 outputs");
@@ -1341,17 +1428,19 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   SDMI_REQUIRE(splits == 1 || a.partial, "conv_gemm: split-K needs a partial buffer");
   SDMI_TRY(conv_gemm_init());
   p.zero = g_zero_page;
-  const int kind = pick_kind(p.M, p.N, p.K, a.dtype, a.geglu != 0);
-  const int rs_parts = a.row_stats_out ? row_stat_parts(p.M, p.N, p.K, a.dtype, a.geglu != 0, a.splits) : 0;
+  const int kind = pick_kind(p.M, p.N, p.K, a.dtype, a.geglu != 0, a.w_rows, a.softmax_seg != 0);
+  SDMI_REQUIRE(kind >= 0, "conv_gemm: no tile shape fits %d rows per sample with N = %d", a.w_rows, p.N);
+  const int rs_parts = a.row_stats_out ? row_stat_parts(p.M, p.N, p.K, a.dtype, a.geglu != 0, a.splits, a.w_rows) : 0;
   // the epilogue leaves the row sums itself when it is the large-tile kernel's wide store (decided below)
   bool rs_in_kernel = false;
   p.wide_store = a.ldo % 8 == 0 && (!a.resid || a.ldr % 8 == 0) && ((uintptr_t)a.out % 16 == 0) &&
                  (!a.resid || (uintptr_t)a.resid % 16 == 0) && (!p.partial || (uintptr_t)p.partial % 16 == 0) &&
                  !(p.out_f32 && p.geglu) && !direct_store_forced();
+  SDMI_REQUIRE(a.w_rows == 0 || p.wide_store, "conv_gemm: per-sample launches need 16-byte addressable operands");
   {
     char label[64];
-    snprintf(label, sizeof(label), "M%d N%d K%d t%d s%d u%d g%d x%d k%d", p.M, p.N, p.K, p.taps, p.stride, p.up,
-             p.geglu, splits, kind);
+    snprintf(label, sizeof(label), "M%d N%d K%d t%d s%d u%d g%d x%d%s k%d", p.M, p.N, p.K, p.taps, p.stride, p.up,
+             p.geglu, splits, p.softmax_seg ? " sm" : (p.w_rows ? " ps" : ""), kind);
     ProfScope prof(PROF_CONV_GEMM, stream, 2.0 * p.M * (double)p.N * p.K,
                    ((double)p.M * p.K / (p.taps == 9 ? 9 : 1) + (double)p.N * p.K + (double)p.M * p.N) * sizeof(T),
                    label);
@@ -1416,6 +1505,10 @@ int conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
 
 int conv_gemm_pick_splits(int M, int N, int K, int dtype, bool geglu) { return make_plan(M, N, K, dtype, geglu).splits; }
 
-int conv_gemm_row_stat_parts(int M, int N, int K, int dtype, bool geglu, int splits) {
-  return row_stat_parts(M, N, K, dtype, geglu, splits);
+int conv_gemm_row_stat_parts(int M, int N, int K, int dtype, bool geglu, int splits, int rows_per_sample) {
+  return row_stat_parts(M, N, K, dtype, geglu, splits, rows_per_sample);
+}
+
+bool conv_gemm_per_sample_ok(int M, int N, int K, int dtype, int rows_per_sample, bool seg) {
+  return rows_per_sample > 0 && make_plan(M, N, K, dtype, false, rows_per_sample, seg).kind >= 0;
 }

@@ -61,13 +61,21 @@ struct ConvGemmArgs {
   // > 0: every output row m is also stored at row m + dup_rows of `out` (two samples that are known to
   // be identical so far are computed once); not with GEGLU or fp32 outputs
   int dup_rows = 0;
+  // > 0: `w` holds one [N][K] matrix per sample, back to back, and output row m uses matrix m / w_rows (token GEMMs
+  // in 16-bit types, no split-K; conv_gemm_per_sample_ok() tells whether a tile shape divides w_rows).  With
+  // vec_per_sample, bias and ln_colsum are per sample as well ([samples][N]).
+  int w_rows = 0;
+  int vec_per_sample = 0;
+  // 1 (per-sample launches only): every 80-column segment of an output row is replaced by its base-2 softmax
+  int softmax_seg = 0;
 };
 int conv_gemm(const ConvGemmArgs& a, hipStream_t stream);
+bool conv_gemm_per_sample_ok(int M, int N, int K, int dtype, int rows_per_sample, bool seg);
 int conv_gemm_init();   // one-time kernel attribute setup; call outside stream capture
 // smallest split count worth using for this shape on a 256-CU part (1 = no split)
 int conv_gemm_pick_splits(int M, int N, int K, int dtype, bool geglu = false);
 // pairs per row that a launch of this shape with `splits` writes to row_stats_out
-int conv_gemm_row_stat_parts(int M, int N, int K, int dtype, bool geglu, int splits);
+int conv_gemm_row_stat_parts(int M, int N, int K, int dtype, bool geglu, int splits, int rows_per_sample = 0);
 
 // ---- normalisation ---------------------------------------------------------------------------
 struct GroupNormArgs {
@@ -183,6 +191,11 @@ int packed_rowsum(const void* wp, float* c, int N, int K, int dtype, hipStream_t
 int pack_inconv_weight(const float* w, float* out, int O, int I, hipStream_t s);
 // OIHW fp32 -> [O][tap][I] fp32 for out_conv
 int pack_outconv_weight(const float* w, float* out, int O, int I, hipStream_t s);
+// cross-attention folded per prompt (xattn_fold.hip): from the cached K | V projections kv [B*ntok][2*d], the
+// gamma-carrying query weights wq [d][d] (rows (head, e)) with qb = Wq beta, and the output weights wo [d][d]:
+// G [B][heads*80][d], g0 [B][heads*80] (pad columns -30000), U [B][d][heads*80]; c0 = scale * log2(e)
+int xattn_fold(const void* kv, const void* wq, const float* qb, const void* wo, void* G, float* g0, void* U, int B,
+               int ntok, int heads, int dh, int d, float c0, int dtype, hipStream_t s);
 // text transformer: x[row][:] = tok[ids[row]][:] + pos[row % T_len][:] (fp32 tables, dtype out); x * sigmoid(1.702 x)
 int embed_tokens(const int64_t* ids, const float* tok, const float* pos, void* out, int rows, int T_len, int d,
                  int vocab, int dtype, hipStream_t s);

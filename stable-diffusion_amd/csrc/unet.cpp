@@ -44,6 +44,11 @@ struct TBlockW {
   // carry gamma); the PackedConv's bias is b' = b + W beta
   float *qkv_c = nullptr, *q2_c = nullptr, *ff1_c = nullptr;
   void* kv_cache = nullptr;        // [B*ntok][2*inner]
+  // cross-attention folded per prompt (16-bit modes): per sample G [heads*80][d] (scores = LayerNorm(x) G^T, keys
+  // padded to 80 per head) with its bias g0 and column sums Gc ([heads*80] each), and U [d][heads*80] (the head
+  // outputs already through to_out); see xattn_fold.hip
+  void *xG = nullptr, *xU = nullptr;
+  float *xg0 = nullptr, *xGc = nullptr;
 };
 
 struct STW {
@@ -61,6 +66,8 @@ struct Layer {
 };
 
 struct SimpleConv { std::string prefix; int ch = 0; PackedConv conv; };
+
+constexpr int XSEG = 80;  // keys per head in the folded cross-attention (xattn_fold.hip)
 
 struct Tensor {           // NHWC activation
   void* p = nullptr;
@@ -117,6 +124,12 @@ struct sdmi_unet {
   bool producer_stats = false;
   float* next_row_stats_out = nullptr;
   int last_rs_parts = 0;
+  // cross-attention as two GEMMs with per-prompt folded weights (decided at finalize: 16-bit modes with the
+  // LayerNorm fold; SDMI_XATTN_FOLD=0 keeps to_q -> attention -> to_out).
+  // next_w_rows / next_vec_per_sample / next_softmax are consumed by the next gemm()
+  bool xfold = false;
+  int xfold_min_d = 640;
+  int next_w_rows = 0, next_vec_per_sample = 0, next_softmax = 0;
 
   // graph replay
   int graph_mode = 1;
@@ -300,6 +313,9 @@ struct sdmi_unet {
       fold_ln = dtype != SDMI_F32 && !(e && atoi(e) == 0);
       const char* e2 = getenv("SDMI_LN_PRODUCER_STATS");
       producer_stats = fold_ln && !(e2 && atoi(e2) == 0);
+      const char* e3 = getenv("SDMI_XATTN_FOLD");
+      xfold = fold_ln && !(e3 && atoi(e3) == 0);
+      if (const char* e4 = getenv("SDMI_XATTN_FOLD_MIN_D")) xfold_min_d = atoi(e4);
     }
     // scratch for one folded fp32 matrix (the widest is the GEGLU projection, 8d x d) and its bias
     float *fold_w = nullptr, *fold_b = nullptr;
@@ -446,6 +462,16 @@ struct sdmi_unet {
         for (auto& tb : st.blocks) {
           if (tb.kv_cache) mem.release(tb.kv_cache);
           SDMI_TRY(mem.alloc(&tb.kv_cache, rows * 2 * st.inner * esz));
+          for (void** q : {&tb.xG, &tb.xU, (void**)&tb.xg0, (void**)&tb.xGc})
+            if (*q) { mem.release(*q); *q = nullptr; }
+          if (xfold && st.inner >= xfold_min_d && ntok <= XSEG && (st.heads * XSEG) % 160 == 0) {
+            const size_t seg_rows = (size_t)batch * st.heads * XSEG;
+            void* q;
+            SDMI_TRY(mem.alloc(&tb.xG, seg_rows * st.inner * esz));
+            SDMI_TRY(mem.alloc(&tb.xU, seg_rows * st.inner * esz));
+            SDMI_TRY(mem.alloc(&q, seg_rows * 4)); tb.xg0 = (float*)q;
+            SDMI_TRY(mem.alloc(&q, seg_rows * 4)); tb.xGc = (float*)q;
+          }
         }
       ctx_batch = batch; ctx_ntok = ntok;
     }
@@ -460,6 +486,14 @@ struct sdmi_unet {
         g.a0 = src; g.c0 = cfg.context_dim; g.w = tb.kv2.w; g.out = tb.kv_cache; g.ldo = 2 * st.inner;
         g.B = 1; g.Hin = 1; g.Win = (int)rows; g.Ho = 1; g.Wo = (int)rows; g.N = 2 * st.inner; g.dtype = dtype;
         SDMI_TRY(conv_gemm(g, s));
+        if (tb.xG) {
+          // scale = dim_head ** -0.5 evaluated in double and rounded to fp32 (as attn() passes it), times log2(e)
+          const float scale = (float)pow((double)st.dh, -0.5);
+          const float c0 = (float)((double)scale * 1.4426950408889634);
+          SDMI_TRY(xattn_fold(tb.kv_cache, tb.q2.w, tb.q2.bias, tb.out2.w, tb.xG, tb.xg0, tb.xU, batch, ntok, st.heads,
+                              st.dh, st.inner, c0, dtype, s));
+          SDMI_TRY(packed_rowsum(tb.xG, tb.xGc, batch * st.heads * XSEG, st.inner, dtype, s));
+        }
       }
     return SDMI_OK;
   }
@@ -484,10 +518,12 @@ struct sdmi_unet {
     g.ln_stats = next_ln_stats; g.ln_colsum = next_ln_colsum; g.ln_nparts = next_ln_nparts;
     next_ln_stats = next_ln_colsum = nullptr; next_ln_nparts = 0;
     g.row_stats_out = next_row_stats_out; next_row_stats_out = nullptr;
+    g.w_rows = next_w_rows; g.vec_per_sample = next_vec_per_sample; g.softmax_seg = next_softmax;
+    next_w_rows = next_vec_per_sample = next_softmax = 0;
     const int M = B * Ho * Wo, K = pc.taps * (c0 + (a1 ? c1 : 0));
-    g.splits = conv_gemm_pick_splits(M, pc.cout, K, dtype, geglu != 0);
+    g.splits = g.w_rows > 0 ? 1 : conv_gemm_pick_splits(M, pc.cout, K, dtype, geglu != 0);
     if (g.splits > 1) g.partial = (float*)ws.get("splitk", (size_t)g.splits * M * pc.cout * 4);
-    last_rs_parts = g.row_stats_out ? conv_gemm_row_stat_parts(M, pc.cout, K, dtype, geglu != 0, g.splits) : 0;
+    last_rs_parts = g.row_stats_out ? conv_gemm_row_stat_parts(M, pc.cout, K, dtype, geglu != 0, g.splits, g.w_rows) : 0;
     if (ws.dry) return SDMI_OK;
     return conv_gemm(g, s);
   }
@@ -581,7 +617,14 @@ struct sdmi_unet {
       SDMI_REQUIRE(xt_parts <= 16, "row statistics: %d parts per row", xt_parts);
       return SDMI_OK;
     };
-    void* qkv = ws.get("qkv", (size_t)rows * 3 * d * esz);
+    const int xseg_n = st.heads * XSEG;                   // width of the folded cross-attention's probability rows
+    // the folded cross-attention needs the folded context and tile shapes that divide a sample's token count
+    // and pays from d = 640 up: the two GEMMs cost 2 (80 + 80) heads d flops per token against 4 d d + 4 ntok d, and
+    // at d = 320 the three-launch path is as fast (measured; SDMI_XATTN_FOLD_MIN_D overrides)
+    const bool xf = xfold && d >= xfold_min_d && !st.blocks.empty() && st.blocks[0].xG != nullptr &&
+                    conv_gemm_per_sample_ok(rows, xseg_n, d, dtype, N, true) &&
+                    conv_gemm_per_sample_ok(rows, d, xseg_n, dtype, N, false);
+    void* qkv = ws.get("qkv", (size_t)rows * std::max(3 * d, xseg_n) * esz);
     void* att = ws.get("att", (size_t)rows * d * esz);
     void* ffm = ws.get("ffm", (size_t)rows * 4 * d * esz);
     y->p = ws.get(out_role, act_bytes(B, H, W, st.ch)); y->H = H; y->W = W; y->C = st.ch;
@@ -617,11 +660,22 @@ struct sdmi_unet {
       SDMI_TRY(attn(qkv, 3 * d, (char*)qkv + (size_t)d * esz, 3 * d, (char*)qkv + (size_t)2 * d * esz, 3 * d, att, d,
                     bq, st.heads, N, N, st.dh, f.s));
       SDMI_TRY(to_xt(att, d, tb.out1, rq, xt, half ? rows_h : 0));
+      if (xf) {
+        // cross-attention as two GEMMs with this prompt's folded weights: probabilities = softmax per head of
+        // LayerNorm(xt) G^T (+ g0) in the first one's epilogue, xt += P U^T + bias in the second
+        PackedConv pg; pg.w = tb.xG; pg.cin = d; pg.cout = xseg_n; pg.taps = 1; pg.bias = tb.xg0;
+        PackedConv pu; pu.w = tb.xU; pu.cin = xseg_n; pu.cout = d; pu.taps = 1; pu.bias = tb.out2.bias;
+        next_w_rows = N; next_vec_per_sample = 1; next_softmax = 1;
+        SDMI_TRY(ln_linear(tb, 1, tb.xGc, pg, qkv, xseg_n, rows, 0, 0));
+        next_w_rows = N;
+        SDMI_TRY(to_xt(qkv, xseg_n, pu, rows, xt, 0));
+      } else {
       // cross-attention against the cached context projections
       SDMI_TRY(ln_linear(tb, 1, tb.q2_c, tb.q2, qkv, d, rq, 0, half ? rows_h : 0));
       SDMI_TRY(attn(qkv, d, tb.kv_cache, 2 * d, (char*)tb.kv_cache + (size_t)d * esz, 2 * d, att, d, B, st.heads, N,
                     ctx_ntok, st.dh, f.s));
       SDMI_TRY(to_xt(att, d, tb.out2, rows, xt, 0));
+      }
       // GEGLU feed-forward
       SDMI_TRY(ln_linear(tb, 2, tb.ff1_c, tb.ff1, ffm, 4 * d, rows, 1, 0));
       SDMI_TRY(to_xt(ffm, 4 * d, tb.ff2, rows, xt, 0, &tb != &st.blocks.back()));

@@ -161,6 +161,36 @@ def test_layernorm_row_sums_with_a_large_common_offset(dt, monkeypatch):
     del nets
 
 
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_cross_attention_fold_equals_the_three_launch_path(dt, monkeypatch):
+    """In the 16-bit modes the cross-attention of a transformer block runs as two GEMMs with weights folded once
+    per prompt (scores = LayerNorm(x) G^T with a per-head softmax in the epilogue, then P U^T + bias + x) in place of
+    to_q -> attention -> to_out.  Same function, other rounding points: the two paths must agree within the block
+    tolerance on maps that take the 256-, 128- and 64-row tiles, and both must stay within it of each other on a
+    map whose token count no tile divides (20x20: both nets take the three-launch path there)."""
+    sdmi = importlib.import_module("stable-diffusion_amd")
+    cfg = S.sd_v1_unet_config(4)
+    nets = []
+    monkeypatch.setenv("SDMI_XATTN_FOLD_MIN_D", "0")          # (by default the 320-wide level keeps three launches)
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SDMI_XATTN_FOLD", flag)
+        net = sdmi.UNetModel(**cfg, compute_dtype=dt)
+        net.load_state_dict(synth.synth_state_dict(net.state_dict_shapes(), 0, device="cuda"))
+        nets.append(net)
+    ctx = g2_u("ctx", (2, 77, 768)).cuda()
+    for name, hw, ch in (("input_blocks.1.1", 64, 320), ("input_blocks.4.1", 32, 640), ("input_blocks.7.1", 16, 1280),
+                         ("middle_block.1", 8, 1280), ("input_blocks.4.1", 20, 640)):
+        idx = _block_index(nets[0], "st", name)
+        x = nhwc(synth.normal(5, f"xf.{name}", (2, ch, hw, hw)), dt)
+        ya = nets[0].run_block("st", idx, x, context=ctx)
+        yb = nets[1].run_block("st", idx, x, context=ctx)
+        torch.cuda.synchronize()
+        err = max_rel_err(ya.float().cpu(), yb.float().cpu())
+        print(f"cross-attention fold {dt} {name} {hw}x{hw}: {err:.3e}")
+        assert err < TOL[dt]
+    del nets
+
+
 def test_q_sample_and_stochastic_encode_g5_bit_exact():
     """LatentDiffusion.q_sample (:3892-3895) with per-sample timesteps and DDIMSampler.stochastic_encode
     (:5378-5391), both with a timestep per sample and with the one-element tensor of inpaint_with_text.py:260."""

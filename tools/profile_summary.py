@@ -9,7 +9,15 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 DOM = "PPShapeILi10ELi2ELi2E"          # mangled fragment of conv_gemm_pp_kernel<half, PPShape<10,2,2>>
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 
-stats = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_bench", "*", "*kernel_stats.csv"))
+
+def newest(pattern):
+    """The most recently written file matching `pattern` (gpurun_out keeps the output of earlier runs, named by
+    process id, next to the latest one)."""
+    files = glob.glob(pattern)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
+stats = newest(os.path.join(ROOT, "gpurun_out", "prof_bench", "*", "*kernel_stats.csv"))
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     keep = [r for r in rows if "at::native" not in r["Name"]]
@@ -39,7 +47,7 @@ if stats:
 def per_launch(dirname, counter):
     """Values of `counter` for the dominant kernel's dispatches, in dispatch order."""
     vals = []
-    for f in glob.glob(os.path.join(ROOT, "gpurun_out", dirname, "*", "*counter_collection.csv")):
+    for f in newest(os.path.join(ROOT, "gpurun_out", dirname, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if DOM in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 vals.append((int(r["Dispatch_Id"]), float(r["Counter_Value"]),
@@ -131,7 +139,7 @@ def classify(k):
 def collect(dirname):
     """class -> counter -> list of per-dispatch values (+ 'dur_us' once per dispatch)."""
     out = {}
-    for f in glob.glob(os.path.join(ROOT, "gpurun_out", dirname, "*", "*counter_collection.csv")):
+    for f in newest(os.path.join(ROOT, "gpurun_out", dirname, "*", "*counter_collection.csv")):
         seen = set()
         for r in csv.DictReader(open(f)):
             c = classify(r["Kernel_Name"])

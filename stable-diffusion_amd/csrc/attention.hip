@@ -113,6 +113,23 @@ template <int D> struct Geo {
   static constexpr int DT32 = NARROW ? DT - 1 : DT;       // full 32-row tiles
 };
 
+// d = 40 (the 64x64 level of the UNet, where most of the attention time goes): the K/V tile goes global -> LDS by
+// LDS-DMA (`buffer_load_dwordx4 ... lds`, ten 1-KiB pieces per 64-key tile shared out over the waves) instead of
+// through registers: no staging registers, no ds_write, one instruction per piece.  A piece lands lane-linearly,
+// so the images are dense and the constant columns the kernel relies on live beside them, written once:
+//   K   [64][80 B]   rows of 5 chunks (odd: conflict-free ds_read_b128); the chunk that carries the (1, 1) columns of
+//                    the folded maximum is ONE constant chunk (KC, and a copy 32 rows further for the second key
+//                    block), which the lanes of the upper half read in the last k-step instead of a row chunk
+//   V03 [64][64 B]   head dims 0..31 (the 32-row output tile)
+//   V4  [64][16 B]   head dims 32..39, and VC [64][16 B] = (1, 0, ..., 0) per key: the ones column and the zero
+//                    padding of the 16-row tile; a lane of the transpose read takes its 8 bytes from V4 or from VC
+// The descriptors end with the last key, so the rows a ragged last tile reads beyond it land as zeros.
+struct Dma40 {
+  static constexpr int V03 = 5120, V4 = 9216, VC = 10304, KC = 11328, KC2 = KC + 32 * 80, STAGE = KC2 + 16;
+  static constexpr int PIECES = 10;       // K: 0..4, V03: 5..8, V4: 9 -- piece p lands at byte 1024 p of the stage
+  static_assert(STAGE % 16 == 0 && VC % 256 == 64 && V4 % 256 == 0, "bank placement of the constant rows");
+};
+
 // NW waves per workgroup (4 or 8): 32 * NW queries share every staged K/V tile
 template <typename T, int D, int NW, bool CAUSAL>
 __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1))) void attn_flash_kernel(FlashParams p) {
@@ -159,24 +176,29 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
   }
 
   // ---- K/V staging -----------------------------------------------------------------------------
-  u32x4 kreg[KC], vreg[KC];
+  constexpr bool DMA = D == 40 && !CAUSAL;
+  constexpr int STAGE_B = DMA ? Dma40::STAGE : G::STAGE;
+  constexpr int KCR = DMA ? 1 : KC;
+  u32x4 kreg[KCR], vreg[KCR];
   const char* kbase = p.k + ((size_t)b * p.Nk * p.ldk + (size_t)hd * D) * sizeof(T);
   const char* vbase = p.v + ((size_t)b * p.Nk * p.ldv + (size_t)hd * D) * sizeof(T);
   // chunk geometry of this thread (clamped so every staging register is always written): byte offsets of its
   // chunks inside a 64-key tile in global memory and in the two LDS images.  The tile's base address is
   // uniform (scalar registers), so a load costs no vector address arithmetic.
-  unsigned kgo[KC], vgo[KC], kso[KC], vso[KC];
-  bool ch_ok[KC];
+  unsigned kgo[KCR], vgo[KCR], kso[KCR], vso[KCR];
+  bool ch_ok[KCR];
+  if constexpr (!DMA) {
 #pragma unroll
-  for (int i = 0; i < KC; ++i) {
-    const int c = tid + i * NT;
-    ch_ok[i] = c < G::NCH;
-    const int cc = ch_ok[i] ? c : G::NCH - 1;
-    const int key = cc / G::CPR, piece = cc - key * G::CPR;
-    kgo[i] = (unsigned)((key * p.ldk + piece * 8) * sizeof(T));
-    vgo[i] = (unsigned)((key * p.ldv + piece * 8) * sizeof(T));
-    kso[i] = key * G::SK + piece * 16;
-    vso[i] = G::KBUF + key * G::SV + piece * 16;
+    for (int i = 0; i < KCR; ++i) {
+      const int c = tid + i * NT;
+      ch_ok[i] = c < G::NCH;
+      const int cc = ch_ok[i] ? c : G::NCH - 1;
+      const int key = cc / G::CPR, piece = cc - key * G::CPR;
+      kgo[i] = (unsigned)((key * p.ldk + piece * 8) * sizeof(T));
+      vgo[i] = (unsigned)((key * p.ldv + piece * 8) * sizeof(T));
+      kso[i] = key * G::SK + piece * 16;
+      vso[i] = G::KBUF + key * G::SV + piece * 16;
+    }
   }
   const int ntiles = (p.Nk + KV_TILE - 1) / KV_TILE;
   // K / V of this (batch, head) through buffer descriptors that end with the last key's row: the tile offset
@@ -188,20 +210,66 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
   const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)vbase, 0, (int)(((size_t)(p.Nk - 1) * p.ldv + D) * sizeof(T)), 0x00020000);
 #define LOAD_TILE(t_)                                                                                     \
-  _Pragma("unroll") for (int i = 0; i < KC; ++i) {                                                     \
+  _Pragma("unroll") for (int i = 0; i < KCR; ++i) {                                                    \
     kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(krs, kgo[i], (t_) * ktile, 0);                        \
     vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vgo[i], (t_) * vtile, 0);                        \
   }
 #define STORE_TILE(buf_)                                                                                  \
   {                                                                                                       \
     char* sb_ = smem + (buf_) * G::STAGE;                                                                 \
-    _Pragma("unroll") for (int i = 0; i < KC; ++i) {                                                   \
+    _Pragma("unroll") for (int i = 0; i < KCR; ++i) {                                                  \
       if (ch_ok[i]) {                                                                                     \
         *reinterpret_cast<u32x4*>(sb_ + kso[i]) = kreg[i];                                                \
         *reinterpret_cast<u32x4*>(sb_ + vso[i]) = vreg[i];                                                \
       }                                                                                                   \
     }                                                                                                     \
   }
+  // LDS-DMA path: piece q = wave + i NW of the tile belongs to this wave; a lane's source offset inside the tile
+  constexpr int PW = (Dma40::PIECES + NW - 1) / NW;
+  unsigned pofs[PW];
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  if constexpr (DMA) {
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      const int q = wu + i * NW;
+      if (q < 5) {                                       // K: chunk (64 q + lane) of the dense [64][5] image
+        const int slot = 64 * q + lane, row = slot / 5;
+        pofs[i] = (unsigned)((row * p.ldk) * sizeof(T) + (slot - 5 * row) * 16);
+      } else if (q < 9) {                                // V03: four chunks per key
+        pofs[i] = (unsigned)(((16 * (q - 5) + (lane >> 2)) * p.ldv) * sizeof(T) + (lane & 3) * 16);
+      } else {                                           // V4: the fifth chunk of every key
+        pofs[i] = (unsigned)((lane * p.ldv) * sizeof(T) + 64);
+      }
+    }
+  }
+  auto dma_tile = [&](const int buf, const int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      const int q = wu + i * NW;
+      if (q < Dma40::PIECES) {
+        auto dst = (__attribute__((address_space(3))) void*)(smem + buf * Dma40::STAGE + q * 1024);
+#if defined(__HIP_DEVICE_COMPILE__)        // (the host pass of the compiler does not know this builtin inside a template)
+        if (q < 5) __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, dst, 16, pofs[i], t * ktile, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, dst, 16, pofs[i], t * vtile, 0, 0);
+#else
+        (void)dst;
+#endif
+      }
+    }
+  };
+  if constexpr (DMA) {
+    // the constant rows of both stages: VC = (1, 0, ..., 0) per key, KC / KC2 = (1, 1, 0, ..., 0)
+    if (tid < 2 * KV_TILE) {
+      T* vc = reinterpret_cast<T*>(smem + (tid >> 6) * Dma40::STAGE + Dma40::VC + (tid & 63) * 16);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vc[e] = (T)(e == 0 ? 1.f : 0.f);
+    }
+    if (tid < 4) {
+      T* kc = reinterpret_cast<T*>(smem + (tid >> 1) * Dma40::STAGE + ((tid & 1) ? Dma40::KC2 : Dma40::KC));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) kc[e] = (T)(e < 2 ? 1.f : 0.f);
+    }
+  } else {
   // zero the over-read tails of both K buffers once (finite operands for the zero-padded Q dims)
   if (tid < 4) {
     const int buf = tid >> 1, part = tid & 1;
@@ -226,6 +294,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
       for (int e = 0; e < G::DT * 32 - D; ++e) reinterpret_cast<T*>(vrow)[e] = (T)(e == 0 ? 1.f : 0.f);
     }
   }
+  }
 
   f32x16 o[G::DT32 > 0 ? G::DT32 : 1];
 #pragma unroll
@@ -236,19 +305,33 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
   f32x4 on[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   float m_run = -INFINITY, l_run = 0.f;
 
-  LOAD_TILE(0)
-  STORE_TILE(0)
+  if constexpr (DMA) {
+    dma_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    LOAD_TILE(0)
+    STORE_TILE(0)
+  }
   __syncthreads();
 
   // transpose-read lane geometry: 16-lane group g covers d columns (g&1)*16.., key rows 4*(g>>1)..;
   // lane i of the group supplies the address of key row i>>2, columns 4*(i&3)..
   const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gcol = ((lane >> 4) & 1) * 16 + gp * 4;
+  // LDS-DMA images: lane parts of the fragment addresses (everything else is an immediate)
+  const int kl = r * 80 + h * 16;                                   // K row chunk 2 s + h, k-steps 0 and 1
+  const int kl2 = h ? Dma40::KC : r * 80 + 64;                      // last k-step: dims 32..39 | the (1, 1) chunk
+  const int vl = Dma40::V03 + (4 * h + gq) * 64 + gcol * 2;         // 32-row tile: key 4 h + gq (+ immediates)
+  const int vnl = (gp < 2 ? Dma40::V4 + gp * 8 : Dma40::VC + (gp - 2) * 8) +
+                  (((lane >> 4) & 1) * 16 + 4 * (lane >> 5) + gq) * 16;   // 16-row tile
 
   // One key tile; BUF (the LDS buffer it reads, compile time) makes every LDS address an immediate offset.
   auto tile = [&](auto bufc, const int t) __attribute__((always_inline)) {
     constexpr int BUF = decltype(bufc)::value;
-    if (t + 1 < ntiles) { LOAD_TILE(t + 1) }
-    const char* kb = smem + BUF * G::STAGE;
+    if (t + 1 < ntiles) {
+      if constexpr (DMA) dma_tile(BUF ^ 1, t + 1);
+      else { LOAD_TILE(t + 1) }
+    }
+    const char* kb = smem + BUF * STAGE_B;
     const char* vb = kb + G::KBUF;
 
     // ---- S^T = K Q^T for the two 32-key blocks ---------------------------------------------------
@@ -257,8 +340,15 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
     for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
 #pragma unroll
     for (int s = 0; s < G::KSTEPS; ++s) {
-      const v8 a0 = *reinterpret_cast<const v8*>(kb + r * G::SK + s * 32 + h * 16);
-      const v8 a1 = *reinterpret_cast<const v8*>(kb + (32 + r) * G::SK + s * 32 + h * 16);
+      v8 a0, a1;
+      if constexpr (DMA) {
+        const int ko = s == G::KSTEPS - 1 ? kl2 : kl + s * 32;
+        a0 = *reinterpret_cast<const v8*>(kb + ko);
+        a1 = *reinterpret_cast<const v8*>(kb + ko + 32 * 80);
+      } else {
+        a0 = *reinterpret_cast<const v8*>(kb + r * G::SK + s * 32 + h * 16);
+        a1 = *reinterpret_cast<const v8*>(kb + (32 + r) * G::SK + s * 32 + h * 16);
+      }
       s0 = Mfma32<T>::mma(a0, qf[s], s0);
       s1 = Mfma32<T>::mma(a1, qf[s], s1);
     }
@@ -362,10 +452,12 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
       const int key0 = (f >> 1) * 32 + (f & 1) * 16 + 4 * h + gq;      // first 4-key block; second is +8
 #pragma unroll
       for (int dt = 0; dt < G::DT32; ++dt) {
-        const char* a0p = vb + key0 * G::SV + (dt * 32 + gcol) * 2;
+        // (DMA images: dt is 0, key0's lane part sits in vl and rows are 64 bytes apart)
+        const char* a0p = DMA ? kb + vl + ((f >> 1) * 32 + (f & 1) * 16) * 64 : vb + key0 * G::SV + (dt * 32 + gcol) * 2;
+        constexpr int HI = DMA ? 8 * 64 : 8 * G::SV;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0p);
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(a0p + 8 * G::SV));
+            (__attribute__((address_space(3))) s16x4*)(a0p + HI));
         s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         o[dt] = Mfma32<T>::mma(__builtin_bit_cast(v8, both), pf[f], o[dt]);
       }
@@ -384,10 +476,11 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
         // lane group g now holds, for query (lane & 15) of either half, the keys 32 bk + 16 (g & 1) + 4 (g >> 1)
         // + {0..3, 8..11}; the V^T operand is fetched in the same order, rows 32 DT32 + (lane & 15)
         const int key0 = bk * 32 + (g & 1) * 16 + 4 * (g >> 1) + gq;
-        const char* a0p = vb + key0 * G::SV + (G::DT32 * 32 + gp * 4) * 2;
+        const char* a0p = DMA ? kb + vnl + bk * 32 * 16 : vb + key0 * G::SV + (G::DT32 * 32 + gp * 4) * 2;
+        constexpr int HI = DMA ? 8 * 16 : 8 * G::SV;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0p);
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(a0p + 8 * G::SV));
+            (__attribute__((address_space(3))) s16x4*)(a0p + HI));
         s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         const v8 av = __builtin_bit_cast(v8, both);
         on[0] = Mfma16<T>::mma(av, __builtin_bit_cast(v8, xu), on[0]);
@@ -395,7 +488,11 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
       }
     }
 
-    if (t + 1 < ntiles) STORE_TILE(BUF ^ 1)
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the next tile have landed
+    } else {
+      if (t + 1 < ntiles) STORE_TILE(BUF ^ 1)
+    }
     __syncthreads();
   };
   {
@@ -473,7 +570,8 @@ int launch_flash(const AttentionArgs& a, hipStream_t stream) {
   p.B = a.B; p.heads = a.heads; p.Nq = a.Nq; p.Nk = a.Nk;
   p.c = a.scale * 1.4426950408889634f;
   p.causal = a.causal;
-  const int lds = 2 * G::STAGE;
+  // (d = 40 non-causal: the LDS-DMA images; the causal variant keeps the register-staged layout)
+  const int lds = 2 * ((D == 40 && !a.causal) ? Dma40::STAGE : G::STAGE);
   // d = 40 at 1024..4096 tokens: 8 waves (256 queries) share every staged K/V tile -- half the staging traffic and
   // barriers per query, measured -5 % at 4096 tokens (16 waves: no better; other head sizes and 9216 tokens: equal or
   // worse).  SDMI_ATTN_WAVES=4/8 overrides for head sizes up to 80 (experiments; read on every call)

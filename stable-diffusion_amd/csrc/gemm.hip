@@ -48,6 +48,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmParams {
   const char* a0; const char* a1; int c0, c1;
+  const char* e0; const char* e1; int ec0, ec1;   // extra pointwise sources behind the taps: K = taps (c0 + c1) + ec0 + ec1,
+                                                  // their rows are the OUTPUT pixels (a 1x1 convolution summed into this one)
   const char* w; char* out; int ldo;
   const float* bias; const float* rowadd; const char* resid; int ldr; int ldra; int out_f32;
   int B, Hin, Win, Ho, Wo, taps, stride, up;
@@ -611,7 +613,9 @@ __device__ __forceinline__ void softmax_seg80(f32x4 (&acc)[NFW][MJ]) {
     }
 }
 
-template <typename T, typename S, bool TI>
+// EX: the instantiation whose K loop continues behind the taps into extra pointwise sources (p.e0 / p.e1); a
+// kernel of its own, because the few extra branches in the loader cost every other launch 2-4 % (measured).
+template <typename T, typename S, bool TI, bool EX = false>
 __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   static_assert(sizeof(T) == 2, "16-bit operands only");
   constexpr int BK = 64, AP = S::AP, NFW = S::NFW, NFP = S::NFP, NPH = S::NPH, NSTAGE = S::NSTAGE, MJ = S::MJ;
@@ -696,8 +700,22 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
 
   const char* acur[AP];         // rows outside the image / beyond M sit on the zero page and do not advance
   int pf_tap, pf_src, pf_left;
+  const int tiles_e0 = EX ? p.ec0 / BK : 0, tiles_e1 = EX ? p.ec1 / BK : 0;      // K-tiles of the extra pointwise sources
   auto set_segment = [&](int tap, int src, int cseg) {
     pf_tap = tap; pf_src = src;
+    if (EX && tap >= p.taps) {
+      // behind the taps: extra source `src`, read at the output pixel itself (no halo, no stride)
+      pf_left = (src ? tiles_e1 : tiles_e0) - cseg;
+      const char* base = src ? p.e1 : p.e0;
+      const int cs = src ? p.ec1 : p.ec0;
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        const size_t pix = pointwise ? (size_t)a_px[i]
+                                     : ((size_t)a_b[i] * p.Ho + (a_px[i] >> 16)) * p.Wo + (a_px[i] & 0xffff);
+        acur[i] = a_b[i] >= 0 ? base + (pix * cs + (size_t)cseg * BK) * sizeof(T) + sc * 16 : zero;
+      }
+      return;
+    }
     pf_left = (src ? tiles_c1 : tiles_c0) - cseg;
     const char* base = src ? p.a1 : p.a0;
     const int cs = src ? p.c1 : p.c0;
@@ -735,7 +753,21 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
     for (int i = 0; i < AP; ++i)
       acur[i] = base + ((size_t)a_px[i] * cs + (size_t)cseg * BK) * sizeof(T) + sc * 16;
   };
+  // tap-inner walk behind its last slice: the extra sources, one K-tile after the other (ti_ex = tiles left in the
+  // current one, 0 while the taps are walked); the rows sit on their own pixel (a_px, stride 1) and the weight
+  // columns follow those of the taps, so the weight offset simply advances by one tile
+  int ti_ex = 0, ti_ex_src = 0;
+  auto set_extra = [&](int src) {
+    ti_ex_src = src;
+    ti_ex = src ? tiles_e1 : tiles_e0;
+    const char* base = src ? p.e1 : p.e0;
+    const int cs = src ? p.ec1 : p.ec0;
+    ti_soff = 0;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) acur[i] = base + ((size_t)a_px[i] * cs) * sizeof(T) + sc * 16;
+  };
   if constexpr (tapinner) {
+    // (the launcher sends launches with extra sources here only unsplit: kt_begin = 0)
     ti_chunk = kt_begin / 9;
     ti_tap = kt_begin - ti_chunk * 9;
     ti_dy = ti_tap / 3;
@@ -744,13 +776,30 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
     wofs = (unsigned)(((size_t)(n0 + wp_first * 8 + lrow) * p.K) * sizeof(T)) + sc * 16 +
            (unsigned)(ti_tap * ctot2 + ti_chunk * (BK * (int)sizeof(T)));
   } else {
-    const int tap = kt_begin / tiles_tap, rem = kt_begin - tap * tiles_tap;
-    const int src = rem >= tiles_c0 ? 1 : 0;
-    set_segment(tap, src, src ? rem - tiles_c0 : rem);
+    int tap = kt_begin / tiles_tap, rem = kt_begin - tap * tiles_tap;
+    if (EX && tap >= p.taps) {             // a split that starts among the extra sources
+      rem = kt_begin - p.taps * tiles_tap;
+      const int src = rem >= tiles_e0 ? 1 : 0;
+      set_segment(p.taps, src, src ? rem - tiles_e0 : rem);
+    } else {
+      const int src = rem >= tiles_c0 ? 1 : 0;
+      set_segment(tap, src, src ? rem - tiles_c0 : rem);
+    }
   }
   auto prefetch_a = [&](int stage) {
     char* abuf = smem + stage * S::STAGE_BYTES;
     if constexpr (tapinner) {
+      if (EX && ti_ex > 0) {
+        // an extra source: every row inside M reads its own pixel (the centre tap's validity bit)
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+          glds16(((unsigned)a_b[i] & 16u) ? acur[i] : zero, abuf + (wid * AP + i) * 1024);
+          acur[i] += BK * sizeof(T);
+        }
+        w_step = (unsigned)(BK * (int)sizeof(T));
+        if (--ti_ex == 0 && ti_ex_src == 0 && tiles_e1 > 0) set_extra(1);
+        return;
+      }
       const unsigned bit = 1u << ti_tap;
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
@@ -761,7 +810,11 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
         w_step = (unsigned)(BK * (int)sizeof(T) - 8 * ctot2);
         ti_tap = 0; ti_dy = 0; ti_dx = 0;
         ++ti_chunk;
-        if (ti_chunk == tiles_c0 && tiles_c1 > 0) {
+        if (EX && ti_chunk == tiles_tap) {
+          // the taps are done: on to the extra sources, whose weight columns start one tile further
+          w_step = (unsigned)(BK * (int)sizeof(T));
+          if (tiles_e0 > 0) set_extra(0);
+        } else if (ti_chunk == tiles_c0 && tiles_c1 > 0) {
           set_source(ti_chunk);
         } else {
           ti_soff = -(long)p.pad * (ti_rowpitch + ti_cs2);
@@ -782,9 +835,9 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
       }
       if (--pf_left == 0) {
         int tap = pf_tap, src = pf_src;
-        if (src == 0 && tiles_c1 > 0) src = 1;
+        if (src == 0 && ((EX && tap >= p.taps) ? tiles_e1 : tiles_c1) > 0) src = 1;
         else { src = 0; ++tap; }
-        if (tap < p.taps) set_segment(tap, src, 0);
+        if (tap < p.taps || (EX && tap == p.taps && tiles_e0 > 0)) set_segment(tap, src, 0);
       }
     }
   };
@@ -1163,27 +1216,51 @@ int set_lds_limits() {
   if constexpr (sizeof(T) == 2) {
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP320, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP320::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP320, false, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP320::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP320, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP320::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP320, true, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP320::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP256, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP256::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP256, false, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP256::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP256, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP256::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP256, true, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP256::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160, false, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP160::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP160::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160, true, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160H::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H, false, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP160H::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP160H::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H, true, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160H::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160Q, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160Q::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160Q, false, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP160Q::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160Q, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP160Q::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160Q, true, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160Q::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP128, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP128::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP128, false, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP128::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP128, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP128::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP128, true, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP128::LDS_BYTES));
   }
   return SDMI_OK;
@@ -1340,6 +1417,7 @@ Plan make_plan(int M, int N, int K, int dtype, bool geglu, int row_unit = 0, boo
 // SDMI_GEMM_TAP_INNER=0/1 overrides where legal (tests and experiments; read on every call).
 bool use_tap_inner(const GemmParams& p) {
   if (p.taps != 9 || p.up) return false;
+  if (p.e0 && p.kt_per_split < p.nkt) return false;      // the tap-inner walk reaches the extra sources only from tile 0
   const char* e = getenv("SDMI_GEMM_TAP_INNER");
   if (e) return atoi(e) != 0;
   return p.tiles_n == 1;
@@ -1365,10 +1443,15 @@ template <typename T, typename S>
 void launch_pp(GemmParams& p, int splits, hipStream_t stream) {
   p.tiles_m = (p.M + S::BM - 1) / S::BM; p.tiles_n = p.N / S::BN;
   const dim3 grid(p.tiles_m * p.tiles_n, splits), block(S::NTHREADS);
-  if (use_tap_inner(p))
+  const bool ti = use_tap_inner(p);
+  if (p.e0) {
+    if (ti) hipLaunchKernelGGL((conv_gemm_pp_kernel<T, S, true, true>), grid, block, S::LDS_BYTES, stream, p);
+    else hipLaunchKernelGGL((conv_gemm_pp_kernel<T, S, false, true>), grid, block, S::LDS_BYTES, stream, p);
+  } else if (ti) {
     hipLaunchKernelGGL((conv_gemm_pp_kernel<T, S, true>), grid, block, S::LDS_BYTES, stream, p);
-  else
+  } else {
     hipLaunchKernelGGL((conv_gemm_pp_kernel<T, S, false>), grid, block, S::LDS_BYTES, stream, p);
+  }
 }
 
 template <typename T>
@@ -1381,7 +1464,8 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   p.ldra = a.ldra > 0 ? a.ldra : (a.ldra < 0 ? 0 : a.N); p.out_f32 = a.out_f32;     // < 0: one row for every sample
   p.B = a.B; p.Hin = a.Hin; p.Win = a.Win; p.Ho = a.Ho; p.Wo = a.Wo;
   p.taps = a.taps; p.stride = a.stride; p.up = a.up; p.pad = a.taps == 9 ? a.pad_lo : 0;
-  p.M = a.B * a.Ho * a.Wo; p.N = a.N; p.K = a.taps * (p.c0 + p.c1); p.geglu = a.geglu;
+  p.e0 = (const char*)a.e0; p.e1 = (const char*)a.e1; p.ec0 = a.e0 ? a.ec0 : 0; p.ec1 = a.e1 ? a.ec1 : 0;
+  p.M = a.B * a.Ho * a.Wo; p.N = a.N; p.K = a.taps * (p.c0 + p.c1) + p.ec0 + p.ec1; p.geglu = a.geglu;
   p.dup_rows = a.dup_rows;
   p.ln_stats = a.ln_stats; p.ln_colsum = a.ln_stats ? a.ln_colsum : nullptr;
   p.ln_nparts = a.ln_nparts; p.ln_eps = a.ln_eps;
@@ -1403,6 +1487,9 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   SDMI_REQUIRE(a.dup_rows == 0 || (a.dup_rows >= p.M && !a.geglu && !a.out_f32),
                "conv_gemm: dup_rows must skip past the computed rows and excludes GEGLU / fp32 outputs");
   SDMI_REQUIRE(a.a0 && a.w && a.out, "conv_gemm: null pointer");
+  SDMI_REQUIRE((!a.e1 || a.e0) && p.ec0 % BK == 0 && p.ec1 % BK == 0 && (!a.e0 || (p.ec0 > 0 && !a.ln_stats && !a.w_rows)),
+               "conv_gemm: extra sources (%d,%d) must be multiples of %d channels, the first one present", p.ec0,
+               p.ec1, BK);
   SDMI_REQUIRE(a.taps == 1 || a.taps == 9, "conv_gemm: taps must be 1 or 9 (got %d)", a.taps);
   SDMI_REQUIRE(a.stride == 1 || a.stride == 2, "conv_gemm: stride must be 1 or 2");
   SDMI_REQUIRE(p.c0 % BK == 0 && p.c1 % BK == 0 && p.c0 > 0,
@@ -1430,6 +1517,8 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   p.zero = g_zero_page;
   const int kind = pick_kind(p.M, p.N, p.K, a.dtype, a.geglu != 0, a.w_rows, a.softmax_seg != 0);
   SDMI_REQUIRE(kind >= 0, "conv_gemm: no tile shape fits %d rows per sample with N = %d", a.w_rows, p.N);
+  SDMI_REQUIRE(!a.e0 || (kind != KIND_SMALL && sizeof(T) == 2),
+               "conv_gemm: extra sources need a large-tile kernel (ask conv_gemm_extra_ok first)");
   const int rs_parts = a.row_stats_out ? row_stat_parts(p.M, p.N, p.K, a.dtype, a.geglu != 0, a.splits, a.w_rows) : 0;
   // the epilogue leaves the row sums itself when it is the large-tile kernel's wide store (decided below)
   bool rs_in_kernel = false;
@@ -1440,7 +1529,7 @@ int launch(const ConvGemmArgs& a, hipStream_t stream) {
   {
     char label[64];
     snprintf(label, sizeof(label), "M%d N%d K%d t%d s%d u%d g%d x%d%s k%d", p.M, p.N, p.K, p.taps, p.stride, p.up,
-             p.geglu, splits, p.softmax_seg ? " sm" : (p.w_rows ? " ps" : ""), kind);
+             p.geglu, splits, p.softmax_seg ? " sm" : (p.w_rows ? " ps" : (p.e0 ? " +e" : "")), kind);
     ProfScope prof(PROF_CONV_GEMM, stream, 2.0 * p.M * (double)p.N * p.K,
                    ((double)p.M * p.K / (p.taps == 9 ? 9 : 1) + (double)p.N * p.K + (double)p.M * p.N) * sizeof(T),
                    label);
@@ -1507,6 +1596,10 @@ int conv_gemm_pick_splits(int M, int N, int K, int dtype, bool geglu) { return m
 
 int conv_gemm_row_stat_parts(int M, int N, int K, int dtype, bool geglu, int splits, int rows_per_sample) {
   return row_stat_parts(M, N, K, dtype, geglu, splits, rows_per_sample);
+}
+
+bool conv_gemm_extra_ok(int M, int N, int K, int dtype) {
+  return dtype != SDMI_F32 && make_plan(M, N, K, dtype, false).kind != KIND_SMALL;
 }
 
 bool conv_gemm_per_sample_ok(int M, int N, int K, int dtype, int rows_per_sample, bool seg) {

@@ -61,6 +61,12 @@ struct ConvGemmArgs {
   // > 0: every output row m is also stored at row m + dup_rows of `out` (two samples that are known to
   // be identical so far are computed once); not with GEGLU or fp32 outputs
   int dup_rows = 0;
+  // extra pointwise sources behind the taps (a 1x1 convolution over other tensors summed into this launch, e.g. a
+  // ResBlock's skip_connection into its second 3x3 convolution): NHWC [B][Ho][Wo][ec0] (and [ec1]), read at the
+  // output pixel; the packed weight rows continue with their columns: K = taps * (c0 + c1) + ec0 + ec1.
+  // 16-bit types on the large-tile kernels only (conv_gemm_extra_ok).
+  const void* e0 = nullptr; const void* e1 = nullptr;
+  int ec0 = 0, ec1 = 0;
   // > 0: `w` holds one [N][K] matrix per sample, back to back, and output row m uses matrix m / w_rows (token GEMMs
   // in 16-bit types, no split-K; conv_gemm_per_sample_ok() tells whether a tile shape divides w_rows).  With
   // vec_per_sample, bias and ln_colsum are per sample as well ([samples][N]).
@@ -70,6 +76,7 @@ struct ConvGemmArgs {
   int softmax_seg = 0;
 };
 int conv_gemm(const ConvGemmArgs& a, hipStream_t stream);
+bool conv_gemm_extra_ok(int M, int N, int K, int dtype);     // K = all columns, the extra sources' included
 bool conv_gemm_per_sample_ok(int M, int N, int K, int dtype, int rows_per_sample, bool seg);
 int conv_gemm_init();   // one-time kernel attribute setup; call outside stream capture
 // smallest split count worth using for this shape on a 256-CU part (1 = no split)

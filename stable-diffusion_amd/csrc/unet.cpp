@@ -31,6 +31,9 @@ struct ResW {
   int cin = 0, cout = 0;
   const float *gn1_g = nullptr, *gn1_b = nullptr, *gn2_g = nullptr, *gn2_b = nullptr;
   PackedConv conv1, conv2, skip;
+  // 16-bit modes: the 1x1 skip_connection as extra K columns of the second 3x3 convolution ([cout][9 cout + cin],
+  // bias = the sum of both), so that skip(x) + conv(h) (stable_diffusion.py:3234) is one launch
+  PackedConv conv2f;
   bool has_skip = false;
   int emb_off = 0;          // column offset into the batched embedding projection
 };
@@ -130,6 +133,9 @@ struct sdmi_unet {
   bool xfold = false;
   int xfold_min_d = 640;
   int next_w_rows = 0, next_vec_per_sample = 0, next_softmax = 0;
+  // extra pointwise sources of the next gemm() (a skip_connection folded into a 3x3 convolution)
+  const void *next_e0 = nullptr, *next_e1 = nullptr;
+  int next_ec0 = 0, next_ec1 = 0;
 
   // graph replay
   int graph_mode = 1;
@@ -369,6 +375,20 @@ struct sdmi_unet {
       SDMI_TRY(P(&r.conv1, p + ".in_layers.2", r.cout, r.cin, 9));
       SDMI_TRY(P(&r.conv2, p + ".out_layers.3", r.cout, r.cout, 9));
       if (r.has_skip) SDMI_TRY(P(&r.skip, p + ".skip_connection", r.cout, r.cin, 1));
+      if (r.has_skip && dtype != SDMI_F32 && !(getenv("SDMI_FUSE_SKIP") && atoi(getenv("SDMI_FUSE_SKIP")) == 0)) {
+        const size_t esz = sdmi_dtype_size(dtype);
+        const size_t k2 = (size_t)9 * r.cout, kf = k2 + r.cin;
+        r.conv2f.cin = r.cout; r.conv2f.cout = r.cout; r.conv2f.taps = 9;
+        SDMI_TRY(mem.alloc(&r.conv2f.w, (size_t)r.cout * kf * esz));
+        SDMI_CHECK_HIP(hipMemcpy2DAsync(r.conv2f.w, kf * esz, r.conv2.w, k2 * esz, k2 * esz, r.cout,
+                                        hipMemcpyDeviceToDevice, s));
+        SDMI_CHECK_HIP(hipMemcpy2DAsync((char*)r.conv2f.w + k2 * esz, kf * esz, r.skip.w, (size_t)r.cin * esz,
+                                        (size_t)r.cin * esz, r.cout, hipMemcpyDeviceToDevice, s));
+        void* fb;
+        SDMI_TRY(mem.alloc(&fb, (size_t)r.cout * 4));
+        SDMI_TRY(axpby(r.conv2.bias, r.skip.bias, 1.0f, 1.0f, (float*)fb, r.cout, s));
+        r.conv2f.bias = (float*)fb;
+      }
       SDMI_CHECK_HIP(hipMemcpyAsync(emb_w_all + (size_t)r.emb_off * temb, store.get(p + ".emb_layers.1.weight"),
                                     (size_t)r.cout * temb * 4, hipMemcpyDeviceToDevice, s));
       SDMI_CHECK_HIP(hipMemcpyAsync(emb_b_all + r.emb_off, store.get(p + ".emb_layers.1.bias"), (size_t)r.cout * 4,
@@ -520,7 +540,9 @@ struct sdmi_unet {
     g.row_stats_out = next_row_stats_out; next_row_stats_out = nullptr;
     g.w_rows = next_w_rows; g.vec_per_sample = next_vec_per_sample; g.softmax_seg = next_softmax;
     next_w_rows = next_vec_per_sample = next_softmax = 0;
-    const int M = B * Ho * Wo, K = pc.taps * (c0 + (a1 ? c1 : 0));
+    g.e0 = next_e0; g.ec0 = next_e0 ? next_ec0 : 0; g.e1 = next_e1; g.ec1 = next_e1 ? next_ec1 : 0;
+    next_e0 = next_e1 = nullptr; next_ec0 = next_ec1 = 0;
+    const int M = B * Ho * Wo, K = pc.taps * (c0 + (a1 ? c1 : 0)) + g.ec0 + g.ec1;
     g.splits = g.w_rows > 0 ? 1 : conv_gemm_pick_splits(M, pc.cout, K, dtype, geglu != 0);
     if (g.splits > 1) g.partial = (float*)ws.get("splitk", (size_t)g.splits * M * pc.cout * 4);
     last_rs_parts = g.row_stats_out ? conv_gemm_row_stat_parts(M, pc.cout, K, dtype, geglu != 0, g.splits, g.w_rows) : 0;
@@ -562,7 +584,14 @@ struct sdmi_unet {
                   nullptr, 0, 0, nullptr, f.s));
     Tensor t1t{t1, H, W, r.cout};
     SDMI_TRY(gn(t1t, nullptr, B, r.gn2_g, r.gn2_b, 1e-5f, 1, nrm, f.s));
-    if (r.has_skip) {
+    if (r.has_skip && r.conv2f.w && conv_gemm_extra_ok(B * H * W, r.cout, 9 * r.cout + cin, dtype)) {
+      // skip_connection(x) + conv(h) as one GEMM: x (both halves of a concatenated input) behind the nine taps
+      next_e0 = x0.p; next_ec0 = x0.C;
+      if (x1) { next_e1 = x1->p; next_ec1 = x1->C; }
+      next_dup_rows = dup_rows;
+      SDMI_TRY(gemm(nrm, r.cout, nullptr, 0, r.conv2f, y->p, r.cout, B, H, W, H, W, 1, 0, nullptr, 0, nullptr, 0, 0,
+                    nullptr, f.s));
+    } else if (r.has_skip) {
       SDMI_TRY(gemm(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, r.skip, y->p, r.cout, B, H, W, H, W, 1, 0,
                     nullptr, 0, nullptr, 0, 0, nullptr, f.s));
       next_dup_rows = dup_rows;

@@ -191,6 +191,36 @@ def test_cross_attention_fold_equals_the_three_launch_path(dt, monkeypatch):
     del nets
 
 
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+def test_skip_connection_folded_into_the_second_convolution(dt, monkeypatch):
+    """ResBlocks that change the channel count return skip_connection(x) + conv(h) (stable_diffusion.py:3234); in
+    the 16-bit modes the 1x1 skip convolution rides as extra K columns of the 3x3 convolution (one launch, one
+    rounding of the sum instead of two).  Against the two-launch path: a block with a concatenated input at 64x64
+    (tap-inner walk), one at 32x32 (tap-major), one at 8x8 (split-K) and one that only changes the width (in4)."""
+    sdmi = importlib.import_module("stable-diffusion_amd")
+    cfg = S.sd_v1_unet_config(4)
+    nets = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SDMI_FUSE_SKIP", flag)
+        net = sdmi.UNetModel(**cfg, compute_dtype=dt)
+        net.load_state_dict(synth.synth_state_dict(net.state_dict_shapes(), 0, device="cuda"))
+        nets.append(net)
+    for name, hw, ch, skip in (("output_blocks.11.0", 64, 320, 320), ("output_blocks.9.0", 64, 640, 320),
+                               ("output_blocks.6.0", 32, 1280, 640), ("output_blocks.1.0", 8, 1280, 1280),
+                               ("input_blocks.4.0", 32, 320, 0), ("output_blocks.5.0", 12, 1280, 640)):
+        idx = _block_index(nets[0], "res", name)
+        x = nhwc(synth.normal(5, f"fs.{name}", (2, ch, hw, hw)), dt)
+        sk = nhwc(synth.normal(6, f"fs.skip.{name}", (2, skip, hw, hw)), dt) if skip else None
+        emb = synth.normal(7, f"fs.emb.{name}", (2, 1280)).cuda()
+        ya = nets[0].run_block("res", idx, x, emb=emb, skip=sk)
+        yb = nets[1].run_block("res", idx, x, emb=emb, skip=sk)
+        torch.cuda.synchronize()
+        err = max_rel_err(ya.float().cpu(), yb.float().cpu())
+        print(f"skip fold {dt} {name} {hw}x{hw}: {err:.3e}")
+        assert err < TOL[dt]
+    del nets
+
+
 def test_q_sample_and_stochastic_encode_g5_bit_exact():
     """LatentDiffusion.q_sample (:3892-3895) with per-sample timesteps and DDIMSampler.stochastic_encode
     (:5378-5391), both with a timestep per sample and with the one-element tensor of inpaint_with_text.py:260."""

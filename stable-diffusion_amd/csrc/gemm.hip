@@ -613,10 +613,14 @@ __device__ __forceinline__ void softmax_seg80(f32x4 (&acc)[NFW][MJ]) {
     }
 }
 
-// EX: the instantiation whose K loop continues behind the taps into extra pointwise sources (p.e0 / p.e1); a
-// kernel of its own, because the few extra branches in the loader cost every other launch 2-4 % (measured).
-template <typename T, typename S, bool TI, bool EX = false>
+// MODE selects what a launch needs beyond the plain GEMM, as instantiations of their own because a few extra
+// branches or address terms in the loader cost every other launch 0.6-4 % (measured): 1 (EX) = the K loop continues
+// behind the taps into extra pointwise sources (p.e0 / p.e1); 2 (PS) = one weight matrix (and bias / column-sum
+// vector) per sample, optional softmax over 80-column segments in the epilogue.
+enum { GEMM_PLAIN = 0, GEMM_EX = 1, GEMM_PS = 2 };
+template <typename T, typename S, bool TI, int MODE = GEMM_PLAIN>
 __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
+  constexpr bool EX = MODE == GEMM_EX, PS = MODE == GEMM_PS;
   static_assert(sizeof(T) == 2, "16-bit operands only");
   constexpr int BK = 64, AP = S::AP, NFW = S::NFW, NFP = S::NFP, NPH = S::NPH, NSTAGE = S::NSTAGE, MJ = S::MJ;
   constexpr int WROWS = 16 * MJ;                                     // rows of a wave's tile
@@ -638,10 +642,10 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
   const int kt_begin = blockIdx.y * p.kt_per_split;
   const int nk = min(p.nkt, kt_begin + p.kt_per_split) - kt_begin;
   // per-sample weights (and bias / column sums): this tile's sample
-  const int smp = p.w_rows > 0 ? __builtin_amdgcn_readfirstlane(m0 / p.w_rows) : 0;
-  const char* const wmat = p.w + (size_t)smp * p.w_stride;
-  const float* const biasv = p.bias ? p.bias + (size_t)smp * p.vec_stride : nullptr;
-  const float* const colsumv = p.ln_colsum ? p.ln_colsum + (size_t)smp * p.vec_stride : nullptr;
+  const int smp = PS && p.w_rows > 0 ? __builtin_amdgcn_readfirstlane(m0 / p.w_rows) : 0;
+  const char* const wmat = PS ? p.w + (size_t)smp * p.w_stride : p.w;
+  const float* const biasv = PS && p.bias ? p.bias + (size_t)smp * p.vec_stride : p.bias;
+  const float* const colsumv = PS && p.ln_colsum ? p.ln_colsum + (size_t)smp * p.vec_stride : p.ln_colsum;
 
   // ---- loader state ----------------------------------------------------------------------------
   const int lrow = lane >> 3;
@@ -1029,7 +1033,7 @@ __global__ __launch_bounds__(512) void conv_gemm_pp_kernel(GemmParams p) {
 #pragma unroll
       for (int j = 0; j < MJ; ++j) acc[i][j] *= ln_r[j];
   }
-  if constexpr (NFW == 5) {       // (the 160-column shapes only: the launcher never sends score GEMMs elsewhere)
+  if constexpr (PS && NFW == 5) {     // (the 160-column shapes only: the launcher never sends score GEMMs elsewhere)
     if (p.softmax_seg) softmax_seg80<NFW, MJ>(acc);
   }
   if (p.wide_store) {
@@ -1216,51 +1220,63 @@ int set_lds_limits() {
   if constexpr (sizeof(T) == 2) {
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP320, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP320::LDS_BYTES));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP320, false, true>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP320, false, GEMM_EX>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP320::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP320, false, GEMM_PS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP320::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP320, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP320::LDS_BYTES));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP320, true, true>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP320, true, GEMM_EX>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP320::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP256, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP256::LDS_BYTES));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP256, false, true>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP256, false, GEMM_EX>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP256::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP256, false, GEMM_PS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP256::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP256, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP256::LDS_BYTES));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP256, true, true>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP256, true, GEMM_EX>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP256::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160::LDS_BYTES));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160, false, true>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160, false, GEMM_EX>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP160::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160, false, GEMM_PS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160::LDS_BYTES));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160, true, true>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160, true, GEMM_EX>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160H::LDS_BYTES));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H, false, true>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H, false, GEMM_EX>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP160H::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H, false, GEMM_PS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160H::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160H::LDS_BYTES));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H, true, true>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160H, true, GEMM_EX>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160H::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160Q, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160Q::LDS_BYTES));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160Q, false, true>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160Q, false, GEMM_EX>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP160Q::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160Q, false, GEMM_PS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160Q::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160Q, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160Q::LDS_BYTES));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160Q, true, true>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP160Q, true, GEMM_EX>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP160Q::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP128, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP128::LDS_BYTES));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP128, false, true>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP128, false, GEMM_EX>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PP128::LDS_BYTES));
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP128, false, GEMM_PS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP128::LDS_BYTES));
     SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP128, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP128::LDS_BYTES));
-    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP128, true, true>,
+    SDMI_CHECK_HIP(hipFuncSetAttribute((const void*)conv_gemm_pp_kernel<T, PP128, true, GEMM_EX>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP128::LDS_BYTES));
   }
   return SDMI_OK;
@@ -1444,9 +1460,11 @@ void launch_pp(GemmParams& p, int splits, hipStream_t stream) {
   p.tiles_m = (p.M + S::BM - 1) / S::BM; p.tiles_n = p.N / S::BN;
   const dim3 grid(p.tiles_m * p.tiles_n, splits), block(S::NTHREADS);
   const bool ti = use_tap_inner(p);
-  if (p.e0) {
-    if (ti) hipLaunchKernelGGL((conv_gemm_pp_kernel<T, S, true, true>), grid, block, S::LDS_BYTES, stream, p);
-    else hipLaunchKernelGGL((conv_gemm_pp_kernel<T, S, false, true>), grid, block, S::LDS_BYTES, stream, p);
+  if (p.w_rows > 0) {
+    hipLaunchKernelGGL((conv_gemm_pp_kernel<T, S, false, GEMM_PS>), grid, block, S::LDS_BYTES, stream, p);
+  } else if (p.e0) {
+    if (ti) hipLaunchKernelGGL((conv_gemm_pp_kernel<T, S, true, GEMM_EX>), grid, block, S::LDS_BYTES, stream, p);
+    else hipLaunchKernelGGL((conv_gemm_pp_kernel<T, S, false, GEMM_EX>), grid, block, S::LDS_BYTES, stream, p);
   } else if (ti) {
     hipLaunchKernelGGL((conv_gemm_pp_kernel<T, S, true>), grid, block, S::LDS_BYTES, stream, p);
   } else {

@@ -55,23 +55,39 @@ template <> struct VecOf<bf16_t> { typedef bf16_t type __attribute__((ext_vector
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// GELU for 16-bit outputs: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the
-// output rounding of fp16 / bf16) -- one rcp, one exp2 and a degree-5 polynomial, no branches.
-__device__ __forceinline__ float gelu_erf_fast(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
-  const float erf_abs = fmaf(-poly * t, e, 1.0f);          // erf(|x| / sqrt 2)
-  const float half_x = 0.5f * x;
-  return fmaf(fabsf(half_x), erf_abs, half_x);               // 0.5 x (1 + sign(x) erf|.|)
+// val * GELU(gate) for the GEGLU epilogues.  16-bit outputs: two values per instruction on the packed fp32 pipe,
+// erf(g / sqrt 2) = g P(g^2) / Q(g^2) with cubic P and Q (fitted on |g| <= 3.3 sqrt 2, where erf has reached
+// 1 - 3e-6; |error| <= 2.7e-6, the result stays inside (-1, 1)): one reciprocal and no exponential per value, about
+// two thirds of the vector instructions of the series form with an exponential (Abramowitz & Stegun 7.1.26) that it
+// replaced (the GELU of a GEGLU projection at M 65536, N 2560 runs with the matrix cores idle: 45 of its 178 us).
+typedef float sdmi_f32x2 __attribute__((ext_vector_type(2)));
+typedef float sdmi_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ sdmi_f32x2 geglu2_fast(sdmi_f32x2 val, sdmi_f32x2 g) {
+  sdmi_f32x2 gc;
+  gc.x = __builtin_amdgcn_fmed3f(g.x, -4.666904755831213f, 4.666904755831213f);
+  gc.y = __builtin_amdgcn_fmed3f(g.y, -4.666904755831213f, 4.666904755831213f);
+  const sdmi_f32x2 t = gc * gc;
+  sdmi_f32x2 p = t * (sdmi_f32x2)(6.622132928e-05f) + (sdmi_f32x2)(7.633776298e-03f);
+  p = p * t + (sdmi_f32x2)(5.445629777e-02f);
+  p = p * t + (sdmi_f32x2)(7.978868118e-01f);
+  sdmi_f32x2 q = t * (sdmi_f32x2)(1.161323832e-03f) + (sdmi_f32x2)(2.368698296e-02f);
+  q = q * t + (sdmi_f32x2)(2.349381700e-01f);
+  q = q * t + (sdmi_f32x2)(1.0f);
+  sdmi_f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(q.x);
+  r.y = __builtin_amdgcn_rcpf(q.y);
+  const sdmi_f32x2 e = (p * gc) * r;                       // erf(g / sqrt 2)
+  const sdmi_f32x2 hv = (val * g) * (sdmi_f32x2)(0.5f);
+  return hv * e + hv;                                      // val * 0.5 g (1 + erf)
 }
-template <typename T> __device__ __forceinline__ float gelu_for(float x) {
-  if constexpr (sizeof(T) == 2) return gelu_erf_fast(x);
-  else return gelu_erf_f(x);
+template <typename T> __device__ __forceinline__ sdmi_f32x4 geglu4_for(sdmi_f32x4 val, sdmi_f32x4 gate) {
+  if constexpr (sizeof(T) == 2) {
+    const sdmi_f32x2 lo = geglu2_fast(val.xy, gate.xy), hi = geglu2_fast(val.zw, gate.zw);
+    return (sdmi_f32x4){lo.x, lo.y, hi.x, hi.y};
+  } else {
+    return (sdmi_f32x4){val.x * gelu_erf_f(gate.x), val.y * gelu_erf_f(gate.y), val.z * gelu_erf_f(gate.z),
+                        val.w * gelu_erf_f(gate.w)};
+  }
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -176,8 +176,7 @@ __device__ __forceinline__ void epilogue_store_geglu(const GemmParams& p, int m,
     val += *reinterpret_cast<const f32x4*>(p.bias + n_val);
     gate += *reinterpret_cast<const f32x4*>(p.bias + n_gate);
   }
-  f32x4 v = {val.x * gelu_for<T>(gate.x), val.y * gelu_for<T>(gate.y), val.z * gelu_for<T>(gate.z),
-             val.w * gelu_for<T>(gate.w)};
+  const f32x4 v = geglu4_for<T>(val, gate);
   T* o = reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n_out;
   typedef T Tx4 __attribute__((ext_vector_type(4)));
   Tx4 ov = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
@@ -303,8 +302,7 @@ __device__ __forceinline__ void store_wave_tile_lds(const GemmParams& p, f32x4 (
       f32x4 v;
       if constexpr (G) {
         const f32x4 val = acc[2 * io][j], gate = acc[2 * io + 1][j];
-        v = (f32x4){val.x * gelu_for<T>(gate.x), val.y * gelu_for<T>(gate.y), val.z * gelu_for<T>(gate.z),
-                    val.w * gelu_for<T>(gate.w)};
+        v = geglu4_for<T>(val, gate);
       } else {
         v = acc[io][j];
       }

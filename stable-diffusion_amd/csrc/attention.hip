@@ -25,6 +25,8 @@
 #include <type_traits>
 
 int attention_scalar(const AttentionArgs& a, hipStream_t stream);
+int attention_f32(const AttentionArgs& a, hipStream_t stream);     // attention_f32.hip
+int attention_f32_init();
 int attention_init();
 
 namespace {
@@ -624,6 +626,7 @@ int attention(const AttentionArgs& a, hipStream_t stream) {
     else rc = dispatch_flash<bf16_t>(a, stream, &handled);
     if (handled) return rc;
   }
+  if (!(a.impl & 1) && a.dtype == SDMI_F32) return attention_f32(a, stream);
   return attention_scalar(a, stream);
 }
 
@@ -657,6 +660,7 @@ int attention_init() {
   if (done) return SDMI_OK;
   SDMI_TRY(init_all<half_t>());
   SDMI_TRY(init_all<bf16_t>());
+  SDMI_TRY(attention_f32_init());
   done = true;
   return SDMI_OK;
 }

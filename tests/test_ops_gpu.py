@@ -345,7 +345,9 @@ def _attn_ref(qv, kv, vv, heads):
 @pytest.mark.parametrize("impl", [0, 1])
 @pytest.mark.parametrize("d,Nq,Nk", [(40, 256, 256), (40, 144, 77), (80, 64, 64), (80, 200, 77), (160, 64, 64),
                                      (160, 36, 77), (40, 1024, 1024), (40, 1100, 1100), (40, 1024, 1100),
-                                     (80, 300, 333)])
+                                     (80, 300, 333),
+                                     # enough workgroups for the fp32 kernel's two-query-tiles-per-wave variant
+                                     (40, 4096, 150), (160, 4100, 50)])
 def test_attention(ops, dt, impl, d, Nq, Nk):
     heads, B = 8, 2
     C = heads * d
@@ -412,7 +414,7 @@ def test_attention_causal(ops, N, d, heads):
         w = (sp(qq) @ sp(kk).transpose(-1, -2)) * d ** -0.5 + mask
         ref = (w.softmax(-1) @ sp(vq)).transpose(1, 2).reshape(B, N, C).float()
         dev = lambda t: t.cuda().to(tdt(dt))
-        for impl in ((1,) if dt == "fp32" else (0, 1)):
+        for impl in (0, 1):         # 0: the matrix-core kernel of the dtype, 1: the vector-ALU kernel
             y = ops.attention(dev(qq), dev(kk), dev(vq), heads, impl=impl, causal=True)
             assert max_rel_err(y.float().cpu(), ref) < TOL[dt] * 2, (dt, impl)
 

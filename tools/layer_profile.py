@@ -21,7 +21,7 @@ def main():
     out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", f"layers_{'vae_' if vae else ''}b{B}.csv")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     lib = _lib.lib()
-    model = pipeline.build_synthetic_model(4, "crossattn", "fp16")
+    model = pipeline.build_synthetic_model(4, "crossattn", os.environ.get("SDMI_PROFILE_DTYPE", "fp16"))
     unet = model.model.diffusion_model
     unet.set_graph_mode(False)
     if sampler_mode:

@@ -301,6 +301,8 @@ int sdmi_conv_out(const void* x, const float* w, const float* bias, float* wpack
 int sdmi_conv2d_splits(int m, int n, int k, int dtype);
 /* softmax(q k^T * scale) v per (batch, head)  (CrossAttention :2784-2796).  impl is a bit set:
  * 1 = force the scalar fp32-math kernel, 2 = causal (query i sees keys 0..i: the text transformer's mask).
+ * Every dtype runs on the matrix cores for head sizes 40, 64, 80, 128, 160 (fp32: fp32 MFMA, 16-byte aligned
+ * pointers and row strides that are multiples of 4 elements; anything else takes the scalar kernel).
  * Row strides are multiples of 8 elements for the 16-bit kernels, and one batch element's K (and V) must span
  * less than 2 GiB (nk * ldk * 2 bytes): the matrix-core kernel addresses them through 32-bit buffer offsets. */
 int sdmi_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,

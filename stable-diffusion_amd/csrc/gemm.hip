@@ -261,10 +261,84 @@ __device__ __forceinline__ void store_wave_tile(const GemmParams& p, f32x4 (&acc
 // With `psum` (16 * CH float2 of LDS private to the wave) the wave also leaves the row sums of what it stores,
 // slot `rs_slot` of the rs_parts pairs of every row: a lane sums its pieces, parks the pair in LDS and lanes 0..15
 // fold one row each in piece order.
+// The same for 16-bit outputs WITHOUT a residual: nothing is added between the accumulators and the store, so the
+// values are rounded on the way INTO the strip (same results, bit for bit) and the strip holds 16-bit rows: half the
+// LDS bytes, 8-byte ds_write in place of the 16-byte one (6-8 cycles against 13 per four values), and the pieces
+// come back out as stored vectors with nothing left to convert.
+template <typename T, int NI, bool G, int MJ>
+__device__ __forceinline__ void store_wave_tile_lds16(const GemmParams& p, f32x4 (&acc)[NI][MJ], T* strip, T* out,
+                                                      int ldo, int m_wave, int n_wave, int lane, float2* psum,
+                                                      int rs_slot) {
+  constexpr int NO = G ? NI / 2 : NI;
+  constexpr int ROWH = NO * 16 + 8;             // row stride in elements (16-byte aligned rows)
+  constexpr int CH = NO * 2;                    // 16-byte pieces per row
+  constexpr int TOTAL = 16 * CH;
+  constexpr int KI = (TOTAL + 63) / 64;
+  typedef T Tx4 __attribute__((ext_vector_type(4)));
+  typedef T Tx8 __attribute__((ext_vector_type(8)));
+  const int frow = lane & 15, fq = lane >> 4;
+  const int n_out = G ? n_wave / 2 : n_wave;
+  int c_row[KI], c_col[KI];
+#pragma unroll
+  for (int k = 0; k < KI; ++k) {
+    const int c = min(lane + 64 * k, TOTAL - 1);
+    c_row[k] = c / CH;
+    c_col[k] = (c - c_row[k] * CH) * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < MJ; ++j) {
+#pragma unroll
+    for (int io = 0; io < NO; ++io) {
+      f32x4 v;
+      if constexpr (G) v = geglu4_for<T>(acc[2 * io][j], acc[2 * io + 1][j]);
+      else v = acc[io][j];
+      const Tx4 h = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
+      *reinterpret_cast<Tx4*>(strip + frow * ROWH + io * 16 + fq * 4) = h;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      const int m = m_wave + j * 16 + c_row[k];
+      const Tx8 o = *reinterpret_cast<const Tx8*>(strip + c_row[k] * ROWH + c_col[k]);
+      if (psum) {
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = to_f32(o[e]); ps += f; pq = fmaf(f, f, pq); }
+        if (lane + 64 * k < TOTAL) psum[lane + 64 * k] = make_float2(ps, pq);
+      }
+      if (lane + 64 * k < TOTAL && m < p.M) {
+        *reinterpret_cast<Tx8*>(out + (size_t)m * ldo + n_out + c_col[k]) = o;
+        if (p.dup_rows > 0) *reinterpret_cast<Tx8*>(out + (size_t)(m + p.dup_rows) * ldo + n_out + c_col[k]) = o;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (psum) {
+      if (lane < 16) {
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { const float2 v = psum[lane * CH + c]; ps += v.x; pq += v.y; }
+        const int m = m_wave + j * 16 + lane;
+        if (m < p.M) {
+          p.rs_out[(size_t)m * p.rs_parts + rs_slot] = make_float2(ps, pq);
+          if (p.dup_rows > 0) p.rs_out[(size_t)(m + p.dup_rows) * p.rs_parts + rs_slot] = make_float2(ps, pq);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 template <typename T, typename OutT, int NI, bool G, int MJ = 4>
 __device__ __forceinline__ void store_wave_tile_lds(const GemmParams& p, f32x4 (&acc)[NI][MJ], float* strip,
                                                     OutT* out, int ldo, int m_wave, int n_wave, int lane,
                                                     float2* psum = nullptr, int rs_slot = 0) {
+  if constexpr (sizeof(OutT) == 2 && sizeof(T) == 2) {
+    if (p.resid == nullptr) {
+      store_wave_tile_lds16<T, NI, G, MJ>(p, acc, reinterpret_cast<T*>(strip), reinterpret_cast<T*>(out), ldo, m_wave,
+                                          n_wave, lane, psum, rs_slot);
+      return;
+    }
+  }
   constexpr int NO = G ? NI / 2 : NI;
   constexpr int ROWF = NO * 16 + 4;
   constexpr int EPC = 16 / (int)sizeof(OutT);   // elements per 16-byte piece

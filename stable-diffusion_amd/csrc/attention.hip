@@ -561,6 +561,244 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
 #undef LOAD_TILE
 #undef STORE_TILE
 
+// Cross-attention over a short key sequence (d = 40, at most 128 keys: the 77 prompt tokens at the 64x64 level).
+// With one or two key tiles per query block the kernel above is a chain of latencies per workgroup (query rows, K/V
+// staging, barrier, stores) around a microsecond of arithmetic.  Here a workgroup stages BOTH key tiles of its
+// (batch, head) once, keeps them in LDS and walks `qpw` consecutive query blocks with them: no staging wait or
+// barrier inside the walk, and the query rows of block i + 1 are in flight while block i is multiplied.  Images,
+// fragments and arithmetic are those of attn_flash_kernel's d = 40 path (tile t lives in stage t).
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW, 16 / NW) void xattn_resident_kernel(FlashParams p, int qpw, int chunks) {
+  constexpr int D = 40;
+  typedef Geo<D> G;
+  typedef typename Mfma32<T>::v8 v8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  // same XCD-aware order as above, over (batch, head, chunk of query blocks)
+  int chunk, bh;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, x = bid & 7;
+    const int id = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (bid >> 3);
+    bh = __builtin_amdgcn_readfirstlane(id / chunks);
+    chunk = id - bh * chunks;
+  }
+  const int b = bh / p.heads, hd = bh - b * p.heads;
+  const int ntiles = (p.Nk + KV_TILE - 1) / KV_TILE;          // 1 or 2 (checked by the launcher)
+
+  const char* kbase = p.k + ((size_t)b * p.Nk * p.ldk + (size_t)hd * D) * sizeof(T);
+  const char* vbase = p.v + ((size_t)b * p.Nk * p.ldv + (size_t)hd * D) * sizeof(T);
+  const unsigned ktile = (unsigned)(KV_TILE * p.ldk * sizeof(T)), vtile = (unsigned)(KV_TILE * p.ldv * sizeof(T));
+  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)kbase, 0, (int)(((size_t)(p.Nk - 1) * p.ldk + D) * sizeof(T)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)vbase, 0, (int)(((size_t)(p.Nk - 1) * p.ldv + D) * sizeof(T)), 0x00020000);
+
+  // the constant rows of both stages (see Dma40), then both tiles by LDS-DMA, piece q = wave + i NW
+  if (tid < 2 * KV_TILE) {
+    T* vc = reinterpret_cast<T*>(smem + (tid >> 6) * Dma40::STAGE + Dma40::VC + (tid & 63) * 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vc[e] = (T)(e == 0 ? 1.f : 0.f);
+  }
+  if (tid < 4) {
+    T* kc = reinterpret_cast<T*>(smem + (tid >> 1) * Dma40::STAGE + ((tid & 1) ? Dma40::KC2 : Dma40::KC));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) kc[e] = (T)(e < 2 ? 1.f : 0.f);
+  }
+  {
+    constexpr int PW = (Dma40::PIECES + NW - 1) / NW;
+    const int wu = __builtin_amdgcn_readfirstlane(wid);
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      const int q = wu + i * NW;
+      if (q < Dma40::PIECES) {
+        unsigned ofs;
+        if (q < 5) {
+          const int slot = 64 * q + lane, row = slot / 5;
+          ofs = (unsigned)((row * p.ldk) * sizeof(T) + (slot - 5 * row) * 16);
+        } else if (q < 9) {
+          ofs = (unsigned)(((16 * (q - 5) + (lane >> 2)) * p.ldv) * sizeof(T) + (lane & 3) * 16);
+        } else {
+          ofs = (unsigned)((lane * p.ldv) * sizeof(T) + 64);
+        }
+        for (int t = 0; t < ntiles; ++t) {
+          auto dst = (__attribute__((address_space(3))) void*)(smem + t * Dma40::STAGE + q * 1024);
+#if defined(__HIP_DEVICE_COMPILE__)
+          if (q < 5) __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, dst, 16, ofs, t * ktile, 0, 0);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, dst, 16, ofs, t * vtile, 0, 0);
+#else
+          (void)dst;
+#endif
+        }
+      }
+    }
+  }
+
+  // query rows of a block, as they lie in memory: dims 16 s + 8 h .. + 7 of this lane's query (zeros beyond d)
+  const int qb_begin = chunk * qpw, qb_end = min(p.qblocks, qb_begin + qpw);
+  const char* qhead = p.q + ((size_t)b * p.Nq * p.ldq + (size_t)hd * D) * sizeof(T);
+  v8 qraw[G::KSTEPS];
+#pragma unroll
+  for (int s = 0; s < G::KSTEPS; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qraw[s][e] = (T)0.f;
+  auto load_q = [&](const int qb) __attribute__((always_inline)) {
+    const int qrow = min(qb * (32 * NW) + wid * 32 + r, p.Nq - 1);
+    const char* qp = qhead + (size_t)qrow * p.ldq * sizeof(T);
+#pragma unroll
+    for (int s = 0; s < G::KSTEPS; ++s) {
+      const int d0 = 16 * s + 8 * h;
+      if (d0 < D) qraw[s] = *reinterpret_cast<const v8*>(qp + d0 * sizeof(T));
+    }
+  };
+  load_q(qb_begin);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, gcol = ((lane >> 4) & 1) * 16 + gp * 4;
+  const int kl = r * 80 + h * 16;
+  const int kl2 = h ? Dma40::KC : r * 80 + 64;
+  const int vl = Dma40::V03 + (4 * h + gq) * 64 + gcol * 2;
+  const int vnl = (gp < 2 ? Dma40::V4 + gp * 8 : Dma40::VC + (gp - 2) * 8) +
+                  (((lane >> 4) & 1) * 16 + 4 * (lane >> 5) + gq) * 16;
+  typedef T Tx4 __attribute__((ext_vector_type(4)));
+
+  for (int qb = qb_begin; qb < qb_end; ++qb) {
+    const int qi = qb * (32 * NW) + wid * 32 + r;
+    v8 qf[G::KSTEPS];
+#pragma unroll
+    for (int s = 0; s < G::KSTEPS; ++s) {
+      const int d0 = 16 * s + 8 * h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[s][e] = d0 < D ? (T)((float)qraw[s][e] * p.c) : (T)0.f;
+    }
+    if (qb + 1 < qb_end) load_q(qb + 1);
+
+    f32x16 o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = 0.f;
+    f32x4 on[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float m_run = 0.f;
+
+    auto tile = [&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
+      const char* kb = smem + t * Dma40::STAGE;
+      f32x16 s0, s1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < G::KSTEPS; ++s) {
+        const int ko = s == G::KSTEPS - 1 ? kl2 : kl + s * 32;
+        const v8 a0 = *reinterpret_cast<const v8*>(kb + ko);
+        const v8 a1 = *reinterpret_cast<const v8*>(kb + ko + 32 * 80);
+        s0 = Mfma32<T>::mma(a0, qf[s], s0);
+        s1 = Mfma32<T>::mma(a1, qf[s], s1);
+      }
+      if (t == ntiles - 1 && (p.Nk & (KV_TILE - 1)) != 0) {
+        const int kbase_i = t * KV_TILE + 4 * h;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = kbase_i + (i & 3) + 8 * (i >> 2);
+          if (key >= p.Nk) s0[i] = -INFINITY;
+          if (key + 32 >= p.Nk) s1[i] = -INFINITY;
+        }
+      }
+      // the accumulators hold score * c - m_run (the maximum rides through the last k-step, see Geo::FOLD)
+      float mx = max3f(s0[0], s0[1], s0[2]), mx1 = max3f(s1[0], s1[1], s1[2]);
+#pragma unroll
+      for (int i = 3; i < 15; i += 2) { mx = max3f(mx, s0[i], s0[i + 1]); mx1 = max3f(mx1, s1[i], s1[i + 1]); }
+      mx = max3f(mx, s0[15], s1[15]);
+      mx = max3f(mx, mx1, mx1);
+      mx = max_halves(mx);
+      if (t == 0 || __any(mx > 8.0f)) {
+        const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+        if (t != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[i] *= alpha;
+          on[0] *= __shfl(alpha, lane & 15, 64);
+          on[1] *= __shfl(alpha, 16 + (lane & 15), 64);
+        }
+        m_run += delta;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] -= delta; s1[i] -= delta; }
+        if (h == 1) {
+          const T hi = (T)(-m_run);
+          const T lo = (T)(-m_run - (float)hi);
+          qf[G::KSTEPS - 1][0] = hi;
+          qf[G::KSTEPS - 1][1] = lo;
+        }
+      }
+      v8 pf[4];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        pf[i >> 3][i & 7] = (T)__builtin_amdgcn_exp2f(s0[i]);
+        pf[2 + (i >> 3)][i & 7] = (T)__builtin_amdgcn_exp2f(s1[i]);
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const char* a0p = kb + vl + ((f >> 1) * 32 + (f & 1) * 16) * 64;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0p);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(a0p + 8 * 64));
+        s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        o = Mfma32<T>::mma(__builtin_bit_cast(v8, both), pf[f], o);
+      }
+#pragma unroll
+      for (int bk = 0; bk < 2; ++bk) {
+        u32x4 xu = __builtin_bit_cast(u32x4, pf[2 * bk]), yu = __builtin_bit_cast(u32x4, pf[2 * bk + 1]);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(xu[w], yu[w], false, false);
+          xu[w] = sw[0]; yu[w] = sw[1];
+        }
+        const char* a0p = kb + vnl + bk * 32 * 16;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0p);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(a0p + 8 * 16));
+        s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const v8 av = __builtin_bit_cast(v8, both);
+        on[0] = Mfma16<T>::mma(av, __builtin_bit_cast(v8, xu), on[0]);
+        on[1] = Mfma16<T>::mma(av, __builtin_bit_cast(v8, yu), on[1]);
+      }
+    };
+    tile(std::integral_constant<int, 0>{});
+    if (ntiles > 1) tile(std::integral_constant<int, 1>{});
+
+    // normalise and store (the ones column is row 8 of the narrow tile: lanes 32.., register 0)
+    const float la = __shfl(on[0][0], 32 + (lane & 15), 64);
+    const float lb = __shfl(on[1][0], 32 + (lane & 15), 64);
+    const float inv = 1.0f / ((r < 16) ? la : lb);
+    if (qi < p.Nq) {
+      char* op = p.out + ((size_t)((size_t)b * p.Nq + qi) * p.ldo + (size_t)hd * D) * sizeof(T);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        Tx4 v = {(T)(o[g4 * 4 + 0] * inv), (T)(o[g4 * 4 + 1] * inv), (T)(o[g4 * 4 + 2] * inv), (T)(o[g4 * 4 + 3] * inv)};
+        *reinterpret_cast<Tx4*>(op + (8 * g4 + 4 * h) * sizeof(T)) = v;
+      }
+    }
+    {
+      const int g = lane >> 4, n = lane & 15;
+      const float inv_a = __shfl(inv, n, 64), inv_b = __shfl(inv, 16 + n, 64);
+      const int d0 = 32 + 4 * g;
+      if (d0 < D) {
+        const int qbase = qi - r;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int q = qbase + 16 * half + n;
+          if (q < p.Nq) {
+            const float iv = half ? inv_b : inv_a;
+            char* op = p.out + ((size_t)((size_t)b * p.Nq + q) * p.ldo + (size_t)hd * D) * sizeof(T);
+            Tx4 v = {(T)(on[half][0] * iv), (T)(on[half][1] * iv), (T)(on[half][2] * iv), (T)(on[half][3] * iv)};
+            *reinterpret_cast<Tx4*>(op + d0 * sizeof(T)) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 template <typename T, int D>
 int launch_flash(const AttentionArgs& a, hipStream_t stream) {
   typedef Geo<D> G;
@@ -577,6 +815,24 @@ int launch_flash(const AttentionArgs& a, hipStream_t stream) {
   // d = 40 at 1024..4096 tokens: 8 waves (256 queries) share every staged K/V tile -- half the staging traffic and
   // barriers per query, measured -5 % at 4096 tokens (16 waves: no better; other head sizes and 9216 tokens: equal or
   // worse).  SDMI_ATTN_WAVES=4/8 overrides for head sizes up to 80 (experiments; read on every call)
+  if constexpr (D == 40) {
+    if (!a.causal && a.Nk <= 2 * KV_TILE) {
+      // short key sequences with enough query blocks to give every workgroup several: K/V stay in LDS for a walk of
+      // qpw blocks (about 1024 workgroups in all, four per CU).  SDMI_XATTN_QPW overrides (experiments; 1 = off)
+      p.qblocks = (a.Nq + 127) / 128;
+      const long blocks = (long)p.qblocks * a.B * a.heads;
+      int qpw = (int)(blocks / 1024);
+      if (qpw > 8) qpw = 8;
+      if (const char* e = getenv("SDMI_XATTN_QPW")) { const int v = atoi(e); if (v >= 1 && v <= 64) qpw = v; }
+      if (qpw >= 2) {
+        const int chunks = (p.qblocks + qpw - 1) / qpw;
+        hipLaunchKernelGGL((xattn_resident_kernel<T, 4>), dim3(chunks * a.B * a.heads), dim3(256), 2 * Dma40::STAGE,
+                           stream, p, qpw, chunks);
+        SDMI_CHECK_HIP(hipGetLastError());
+        return SDMI_OK;
+      }
+    }
+  }
   int nw = (D == 40 && a.Nq >= 1024 && a.Nq <= 4096 && a.Nk >= 1024) ? 8 : 4;
   if (const char* e = getenv("SDMI_ATTN_WAVES")) { const int v = atoi(e); if ((v == 4 || v == 8) && D <= 80) nw = v; }
   if (a.causal) nw = 4;                    // the causal variant exists for 4-wave workgroups only

@@ -366,6 +366,35 @@ def test_attention(ops, dt, impl, d, Nq, Nk):
         assert torch.equal(y2, y)
 
 
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("Nq,Nk,qpw", [(16384 + 70, 77, None), (1000, 77, 3), (1024, 64, 8), (700, 128, 2),
+                                       (512, 20, 5), (130, 100, 64)])
+def test_attention_short_keys_resident(ops, monkeypatch, dt, Nq, Nk, qpw):
+    """d = 40 with at most 128 keys (the prompt tokens at the 64x64 level): the variant that keeps both key tiles in
+    LDS and walks several query blocks per workgroup.  qpw None: the launcher's own choice (enough blocks for 2 per
+    workgroup, ragged last block and last chunk); otherwise forced.  Same arithmetic as the one-block-per-workgroup
+    kernel, so the two must agree bit for bit; a spiked key in the second tile forces the rescale path."""
+    heads, B, d = 8, 2, 40
+    C = heads * d
+    qv = q(rnd("attres.q", (B, Nq, C), -2., 2.), dt)
+    kv = rnd("attres.k", (B, Nk, C), -2., 2.)
+    if Nk > 70:
+        kv[:, 70] = qv[:, 5].float() * 4.0
+    kv = q(kv, dt)
+    vv = q(rnd("attres.v", (B, Nk, C), -1., 1.), dt)
+    ref = _attn_ref(qv, kv, vv, heads)
+    dev = lambda t: t.cuda().to(tdt(dt))
+    monkeypatch.setenv("SDMI_XATTN_QPW", "1")
+    y1 = ops.attention(dev(qv), dev(kv), dev(vv), heads)
+    if qpw is None:
+        monkeypatch.delenv("SDMI_XATTN_QPW")
+    else:
+        monkeypatch.setenv("SDMI_XATTN_QPW", str(qpw))
+    y = ops.attention(dev(qv), dev(kv), dev(vv), heads)
+    assert max_rel_err(y.float().cpu(), ref) < TOL[dt] * 2
+    assert torch.equal(y, y1)
+
+
 def test_attention_forced_rescale(ops):
     """A key far above the running max late in the sequence forces the online-softmax rescale path."""
     heads, B, d, N = 8, 1, 40, 256

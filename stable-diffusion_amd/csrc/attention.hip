@@ -57,6 +57,16 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+// A vector instruction may read MFMA accumulators only once the matrix pipe has written them (8 passes plus 4 issue
+// slots after a 32x32x16 product on gfx950; reading earlier returns the OLD register contents, not a stall).  The
+// compiler keeps that distance for the instructions it emits itself but does not look inside inline assembly, so
+// the first max3f that reads fresh accumulators is preceded by this.
+__device__ __forceinline__ void mfma_settle(f32x16& a, f32x16& b) {
+  asm volatile("s_nop 7\n\ts_nop 4" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void mfma_settle(f32x16& a) {
+  asm volatile("s_nop 7\n\ts_nop 4" : "+v"(a));
+}
 // max over the two 32-lane halves of the wave, left in every lane (one lane-swap instead of an LDS round trip)
 __device__ __forceinline__ float max_halves(float v) {
   const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -380,6 +390,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
     // The running maximum only moves when some query of the wave outgrows it by more than 2^8: P stays
     // below 256 (exact range of both 16-bit formats, fp32 sums), and almost every tile skips the
     // rescale of the output accumulators.
+    mfma_settle(s0, s1);
     float mx = max3f(s0[0], s0[1], s0[2]), mx1 = max3f(s1[0], s1[1], s1[2]);
 #pragma unroll
     for (int i = 3; i < 15; i += 2) { mx = max3f(mx, s0[i], s0[i + 1]); mx1 = max3f(mx1, s1[i], s1[i + 1]); }
@@ -567,7 +578,9 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? 16 / NW : (D <= 80 ? 8 / NW : 1
 // (batch, head) once, keeps them in LDS and walks `qpw` consecutive query blocks with them: no staging wait or
 // barrier inside the walk, and the query rows of block i + 1 are in flight while block i is multiplied.  Images,
 // fragments and arithmetic are those of attn_flash_kernel's d = 40 path (tile t lives in stage t).
-template <typename T, int NW>
+// T1: what the second key tile holds -- 0 nothing (at most 64 keys), 1 its first 32-key block only (at most 96
+// keys: the 77 prompt tokens; the other block's products are skipped), 2 both blocks.
+template <typename T, int NW, int T1>
 __global__ __launch_bounds__(64 * NW, 16 / NW) void xattn_resident_kernel(FlashParams p, int qpw, int chunks) {
   constexpr int D = 40;
   typedef Geo<D> G;
@@ -585,7 +598,7 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void xattn_resident_kernel(FlashP
     chunk = id - bh * chunks;
   }
   const int b = bh / p.heads, hd = bh - b * p.heads;
-  const int ntiles = (p.Nk + KV_TILE - 1) / KV_TILE;          // 1 or 2 (checked by the launcher)
+  constexpr int ntiles = T1 == 0 ? 1 : 2;
 
   const char* kbase = p.k + ((size_t)b * p.Nk * p.ldk + (size_t)hd * D) * sizeof(T);
   const char* vbase = p.v + ((size_t)b * p.Nk * p.ldv + (size_t)hd * D) * sizeof(T);
@@ -635,21 +648,32 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void xattn_resident_kernel(FlashP
     }
   }
 
-  // query rows of a block, as they lie in memory: dims 16 s + 8 h .. + 7 of this lane's query (zeros beyond d)
+  // Query rows and output rows travel as 16-byte chunks in memory order (chunk c = lane + 64 i of the wave's
+  // 32 rows x 80 bytes: a load or store instruction covers 13 rows' contiguous 80 bytes instead of 64 separate
+  // lines) and change to and from the fragment layout through a 2560-byte LDS image owned by the wave.
   const int qb_begin = chunk * qpw, qb_end = min(p.qblocks, qb_begin + qpw);
   const char* qhead = p.q + ((size_t)b * p.Nq * p.ldq + (size_t)hd * D) * sizeof(T);
-  v8 qraw[G::KSTEPS];
+  char* const ohead = p.out + ((size_t)b * p.Nq * p.ldo + (size_t)hd * D) * sizeof(T);
+  char* const wimg = smem + 2 * Dma40::STAGE + wid * (32 * 80);
+  constexpr int QCH = 3;                                     // 160 chunks = 2.5 x 64 lanes
+  int crow[QCH], cofs[QCH];
 #pragma unroll
-  for (int s = 0; s < G::KSTEPS; ++s)
+  for (int i = 0; i < QCH; ++i) {
+    const int c = lane + 64 * i;
+    crow[i] = c / 5;
+    cofs[i] = (c - 5 * crow[i]) * 16;
+  }
+  u32x4 qraw[QCH];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qraw[s][e] = (T)0.f;
+  for (int i = 0; i < QCH; ++i) qraw[i] = (u32x4){0u, 0u, 0u, 0u};
   auto load_q = [&](const int qb) __attribute__((always_inline)) {
-    const int qrow = min(qb * (32 * NW) + wid * 32 + r, p.Nq - 1);
-    const char* qp = qhead + (size_t)qrow * p.ldq * sizeof(T);
+    const int row0 = qb * (32 * NW) + wid * 32;
 #pragma unroll
-    for (int s = 0; s < G::KSTEPS; ++s) {
-      const int d0 = 16 * s + 8 * h;
-      if (d0 < D) qraw[s] = *reinterpret_cast<const v8*>(qp + d0 * sizeof(T));
+    for (int i = 0; i < QCH; ++i) {
+      if (lane + 64 * i < 160) {
+        const int qrow = min(row0 + crow[i], p.Nq - 1);
+        qraw[i] = *reinterpret_cast<const u32x4*>(qhead + (size_t)qrow * p.ldq * sizeof(T) + cofs[i]);
+      }
     }
   };
   load_q(qb_begin);
@@ -665,14 +689,27 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void xattn_resident_kernel(FlashP
   typedef T Tx4 __attribute__((ext_vector_type(4)));
 
   for (int qb = qb_begin; qb < qb_end; ++qb) {
-    const int qi = qb * (32 * NW) + wid * 32 + r;
+    const int row0 = qb * (32 * NW) + wid * 32;
+#pragma unroll
+    for (int i = 0; i < QCH; ++i)
+      if (lane + 64 * i < 160) *reinterpret_cast<u32x4*>(wimg + 16 * (lane + 64 * i)) = qraw[i];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
     v8 qf[G::KSTEPS];
 #pragma unroll
     for (int s = 0; s < G::KSTEPS; ++s) {
       const int d0 = 16 * s + 8 * h;
+      if (d0 < D) {
+        const v8 raw = *reinterpret_cast<const v8*>(wimg + r * 80 + d0 * sizeof(T));
 #pragma unroll
-      for (int e = 0; e < 8; ++e) qf[s][e] = d0 < D ? (T)((float)qraw[s][e] * p.c) : (T)0.f;
+        for (int e = 0; e < 8; ++e) qf[s][e] = (T)((float)raw[e] * p.c);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[s][e] = (T)0.f;
+      }
     }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
     if (qb + 1 < qb_end) load_q(qb + 1);
 
     f32x16 o;
@@ -681,8 +718,10 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void xattn_resident_kernel(FlashP
     f32x4 on[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float m_run = 0.f;
 
-    auto tile = [&](auto tc) __attribute__((always_inline)) {
+    // HALF: only the first 32 keys of the tile exist (77 keys: 13 of them in tile 1), the second key block is skipped
+    auto tile = [&](auto tc, auto hc) __attribute__((always_inline)) {
       constexpr int t = decltype(tc)::value;
+      constexpr bool HALF = decltype(hc)::value;
       const char* kb = smem + t * Dma40::STAGE;
       f32x16 s0, s1;
 #pragma unroll
@@ -693,7 +732,7 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void xattn_resident_kernel(FlashP
         const v8 a0 = *reinterpret_cast<const v8*>(kb + ko);
         const v8 a1 = *reinterpret_cast<const v8*>(kb + ko + 32 * 80);
         s0 = Mfma32<T>::mma(a0, qf[s], s0);
-        s1 = Mfma32<T>::mma(a1, qf[s], s1);
+        if constexpr (!HALF) s1 = Mfma32<T>::mma(a1, qf[s], s1);
       }
       if (t == ntiles - 1 && (p.Nk & (KV_TILE - 1)) != 0) {
         const int kbase_i = t * KV_TILE + 4 * h;
@@ -705,11 +744,19 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void xattn_resident_kernel(FlashP
         }
       }
       // the accumulators hold score * c - m_run (the maximum rides through the last k-step, see Geo::FOLD)
-      float mx = max3f(s0[0], s0[1], s0[2]), mx1 = max3f(s1[0], s1[1], s1[2]);
+      if constexpr (HALF) mfma_settle(s0); else mfma_settle(s0, s1);
+      float mx = max3f(s0[0], s0[1], s0[2]);
+      if constexpr (HALF) {
 #pragma unroll
-      for (int i = 3; i < 15; i += 2) { mx = max3f(mx, s0[i], s0[i + 1]); mx1 = max3f(mx1, s1[i], s1[i + 1]); }
-      mx = max3f(mx, s0[15], s1[15]);
-      mx = max3f(mx, mx1, mx1);
+        for (int i = 3; i < 15; i += 2) mx = max3f(mx, s0[i], s0[i + 1]);
+        mx = max3f(mx, s0[15], s0[15]);
+      } else {
+        float mx1 = max3f(s1[0], s1[1], s1[2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) { mx = max3f(mx, s0[i], s0[i + 1]); mx1 = max3f(mx1, s1[i], s1[i + 1]); }
+        mx = max3f(mx, s0[15], s1[15]);
+        mx = max3f(mx, mx1, mx1);
+      }
       mx = max_halves(mx);
       if (t == 0 || __any(mx > 8.0f)) {
         const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
@@ -722,7 +769,7 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void xattn_resident_kernel(FlashP
         }
         m_run += delta;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { s0[i] -= delta; s1[i] -= delta; }
+        for (int i = 0; i < 16; ++i) { s0[i] -= delta; if constexpr (!HALF) s1[i] -= delta; }
         if (h == 1) {
           const T hi = (T)(-m_run);
           const T lo = (T)(-m_run - (float)hi);
@@ -734,10 +781,10 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void xattn_resident_kernel(FlashP
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         pf[i >> 3][i & 7] = (T)__builtin_amdgcn_exp2f(s0[i]);
-        pf[2 + (i >> 3)][i & 7] = (T)__builtin_amdgcn_exp2f(s1[i]);
+        if constexpr (!HALF) pf[2 + (i >> 3)][i & 7] = (T)__builtin_amdgcn_exp2f(s1[i]);
       }
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
+      for (int f = 0; f < (HALF ? 2 : 4); ++f) {
         const char* a0p = kb + vl + ((f >> 1) * 32 + (f & 1) * 16) * 64;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0p);
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -746,7 +793,7 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void xattn_resident_kernel(FlashP
         o = Mfma32<T>::mma(__builtin_bit_cast(v8, both), pf[f], o);
       }
 #pragma unroll
-      for (int bk = 0; bk < 2; ++bk) {
+      for (int bk = 0; bk < (HALF ? 1 : 2); ++bk) {
         u32x4 xu = __builtin_bit_cast(u32x4, pf[2 * bk]), yu = __builtin_bit_cast(u32x4, pf[2 * bk + 1]);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -763,39 +810,44 @@ __global__ __launch_bounds__(64 * NW, 16 / NW) void xattn_resident_kernel(FlashP
         on[1] = Mfma16<T>::mma(av, __builtin_bit_cast(v8, yu), on[1]);
       }
     };
-    tile(std::integral_constant<int, 0>{});
-    if (ntiles > 1) tile(std::integral_constant<int, 1>{});
+    tile(std::integral_constant<int, 0>{}, std::false_type{});
+    if constexpr (T1 == 1) tile(std::integral_constant<int, 1>{}, std::true_type{});
+    // (two full tiles in one basic block make the register allocator spill: the branch, always taken, keeps them apart)
+    if constexpr (T1 == 2) { if (p.Nk > KV_TILE) tile(std::integral_constant<int, 1>{}, std::false_type{}); }
 
     // normalise and store (the ones column is row 8 of the narrow tile: lanes 32.., register 0)
     const float la = __shfl(on[0][0], 32 + (lane & 15), 64);
     const float lb = __shfl(on[1][0], 32 + (lane & 15), 64);
     const float inv = 1.0f / ((r < 16) ? la : lb);
-    if (qi < p.Nq) {
-      char* op = p.out + ((size_t)((size_t)b * p.Nq + qi) * p.ldo + (size_t)hd * D) * sizeof(T);
+    // fragments -> the wave's image (rows of queries that do not exist are written too and never stored)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        Tx4 v = {(T)(o[g4 * 4 + 0] * inv), (T)(o[g4 * 4 + 1] * inv), (T)(o[g4 * 4 + 2] * inv), (T)(o[g4 * 4 + 3] * inv)};
-        *reinterpret_cast<Tx4*>(op + (8 * g4 + 4 * h) * sizeof(T)) = v;
-      }
+    for (int g4 = 0; g4 < 4; ++g4) {
+      Tx4 v = {(T)(o[g4 * 4 + 0] * inv), (T)(o[g4 * 4 + 1] * inv), (T)(o[g4 * 4 + 2] * inv), (T)(o[g4 * 4 + 3] * inv)};
+      *reinterpret_cast<Tx4*>(wimg + r * 80 + (8 * g4 + 4 * h) * sizeof(T)) = v;
     }
     {
       const int g = lane >> 4, n = lane & 15;
       const float inv_a = __shfl(inv, n, 64), inv_b = __shfl(inv, 16 + n, 64);
-      const int d0 = 32 + 4 * g;
-      if (d0 < D) {
-        const int qbase = qi - r;
+      if (g < 2) {                                   // dims 32 + 4 g .. + 3 of queries n and 16 + n
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-          const int q = qbase + 16 * half + n;
-          if (q < p.Nq) {
-            const float iv = half ? inv_b : inv_a;
-            char* op = p.out + ((size_t)((size_t)b * p.Nq + q) * p.ldo + (size_t)hd * D) * sizeof(T);
-            Tx4 v = {(T)(on[half][0] * iv), (T)(on[half][1] * iv), (T)(on[half][2] * iv), (T)(on[half][3] * iv)};
-            *reinterpret_cast<Tx4*>(op + d0 * sizeof(T)) = v;
-          }
+          const float iv = half ? inv_b : inv_a;
+          Tx4 v = {(T)(on[half][0] * iv), (T)(on[half][1] * iv), (T)(on[half][2] * iv), (T)(on[half][3] * iv)};
+          *reinterpret_cast<Tx4*>(wimg + (16 * half + n) * 80 + (32 + 4 * g) * sizeof(T)) = v;
         }
       }
     }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < QCH; ++i) {
+      if (lane + 64 * i < 160 && row0 + crow[i] < p.Nq) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(wimg + 16 * (lane + 64 * i));
+        *reinterpret_cast<u32x4*>(ohead + (size_t)(row0 + crow[i]) * p.ldo * sizeof(T) + cofs[i]) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
   }
 }
 
@@ -816,7 +868,7 @@ int launch_flash(const AttentionArgs& a, hipStream_t stream) {
   // barriers per query, measured -5 % at 4096 tokens (16 waves: no better; other head sizes and 9216 tokens: equal or
   // worse).  SDMI_ATTN_WAVES=4/8 overrides for head sizes up to 80 (experiments; read on every call)
   if constexpr (D == 40) {
-    if (!a.causal && a.Nk <= 2 * KV_TILE) {
+    if (!a.causal && a.Nk <= 2 * KV_TILE && a.ldo % 8 == 0) {
       // short key sequences with enough query blocks to give every workgroup several: K/V stay in LDS for a walk of
       // qpw blocks (about 1024 workgroups in all, four per CU).  SDMI_XATTN_QPW overrides (experiments; 1 = off)
       p.qblocks = (a.Nq + 127) / 128;
@@ -826,8 +878,11 @@ int launch_flash(const AttentionArgs& a, hipStream_t stream) {
       if (const char* e = getenv("SDMI_XATTN_QPW")) { const int v = atoi(e); if (v >= 1 && v <= 64) qpw = v; }
       if (qpw >= 2) {
         const int chunks = (p.qblocks + qpw - 1) / qpw;
-        hipLaunchKernelGGL((xattn_resident_kernel<T, 4>), dim3(chunks * a.B * a.heads), dim3(256), 2 * Dma40::STAGE,
-                           stream, p, qpw, chunks);
+        const dim3 grid(chunks * a.B * a.heads), block(256);
+        const int lds = 2 * Dma40::STAGE + 4 * 32 * 80;
+        if (a.Nk <= KV_TILE) hipLaunchKernelGGL((xattn_resident_kernel<T, 4, 0>), grid, block, lds, stream, p, qpw, chunks);
+        else if (a.Nk <= KV_TILE + 32) hipLaunchKernelGGL((xattn_resident_kernel<T, 4, 1>), grid, block, lds, stream, p, qpw, chunks);
+        else hipLaunchKernelGGL((xattn_resident_kernel<T, 4, 2>), grid, block, lds, stream, p, qpw, chunks);
         SDMI_CHECK_HIP(hipGetLastError());
         return SDMI_OK;
       }

@@ -395,6 +395,24 @@ def test_attention_short_keys_resident(ops, monkeypatch, dt, Nq, Nk, qpw):
     assert torch.equal(y, y1)
 
 
+@pytest.mark.parametrize("d", [40, 64, 80, 160])
+@pytest.mark.parametrize("Nq,Nk", [(256, 1024), (512, 77)])
+def test_attention_large_common_score(ops, d, Nq, Nk):
+    """Every score near +110 (in base-2 units): the running maximum is far above any partial dot product, so a
+    maximum taken from accumulators the matrix pipe has not finished writing would move the reference point by
+    tens of units and flush the probabilities to zero.  Also: two calls agree bit for bit."""
+    heads, B, a = 8, 1, 3.5
+    C = heads * d
+    qv = q(a + 0.05 * rnd(f"attbig{d}.q", (B, Nq, C), -1., 1.), "fp16")
+    kv = q(a * (40.0 / d) ** 0.75 + 0.05 * rnd(f"attbig{d}.k", (B, Nk, C), -1., 1.), "fp16")
+    vv = q(rnd(f"attbig{d}.v", (B, Nk, C), -1., 1.), "fp16")
+    ref = _attn_ref(qv, kv, vv, heads)
+    dev = lambda t: t.cuda().half()
+    y = ops.attention(dev(qv), dev(kv), dev(vv), heads)
+    assert max_rel_err(y.float().cpu(), ref) < TOL["fp16"] * 2
+    assert torch.equal(y, ops.attention(dev(qv), dev(kv), dev(vv), heads))
+
+
 def test_attention_forced_rescale(ops):
     """A key far above the running max late in the sequence forces the online-softmax rescale path."""
     heads, B, d, N = 8, 1, 40, 256

@@ -25,7 +25,7 @@ timeout -k 10 200 python3 $R/bench.py $SHORT > $R/gpurun_out/pmc_labels.log 2>&1
 unset SDMI_BENCH_LABELS
 pass fetch "conv_gemm" FETCH_SIZE
 pass write "conv_gemm" WRITE_SIZE
-pass sq "conv_gemm|attn_flash|cross_attn" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE
+pass sq "conv_gemm|attn_flash|xattn_resident" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE
 pass norm_fetch "gn_|layernorm" FETCH_SIZE
 pass norm_write "gn_|layernorm" WRITE_SIZE GRBM_GUI_ACTIVE
 grep '"metric"' $R/gpurun_out/prof_bench.log | tail -n 1 | cut -c1-400

@@ -123,6 +123,8 @@ def classify(k):
         return "conv_gemm 128x128"
     if "attn_flash" in k:
         return "attn_flash"
+    if "xattn_resident" in k:
+        return "xattn_resident"
     if "cross_attn" in k:
         return "cross_attn"
     if "gn_partial" in k:

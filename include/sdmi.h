@@ -304,7 +304,9 @@ int sdmi_conv2d_splits(int m, int n, int k, int dtype);
  * Every dtype runs on the matrix cores for head sizes 40, 64, 80, 128, 160 (fp32: fp32 MFMA, 16-byte aligned
  * pointers and row strides that are multiples of 4 elements; anything else takes the scalar kernel).
  * Row strides are multiples of 8 elements for the 16-bit kernels, and one batch element's K (and V) must span
- * less than 2 GiB (nk * ldk * 2 bytes): the matrix-core kernel addresses them through 32-bit buffer offsets. */
+ * less than 2 GiB (nk * ldk * 2 bytes): the matrix-core kernel addresses them through 32-bit buffer offsets.
+ * (Head size 40 with at most 128 keys and 2048 or more 128-query blocks in all runs a variant that stages K/V once
+ * per workgroup; its results equal the general kernel's bit for bit.) */
 int sdmi_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
                    int batch, int heads, int nq, int nk, int d, float scale, int dtype, int impl, void* stream);
 /* timestep_embedding :2212-2232 (fp32 out [batch][dim]) */

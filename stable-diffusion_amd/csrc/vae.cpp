@@ -255,6 +255,23 @@ struct VaeNet {
     SDMI_TRY(gemm(nrm, C, a.q.w, a.q.bias, C, 1, q, C, 1, 1, B * N, 1, B * N, 0, nullptr, 0, 0, s));
     SDMI_TRY(gemm(nrm, C, a.k.w, a.k.bias, C, 1, k, C, 1, 1, B * N, 1, B * N, 0, nullptr, 0, 0, s));
     const float scale = (float)pow((double)C, -0.5);
+    // The P v product below contracts over the tokens in whole K-tiles.  Token counts that are not (a latent whose
+    // H * W is no multiple of 64; never the case behind the UNet, whose latents are multiples of 8 per side, but the
+    // reference's autoencoder takes any size): v as a plain projection and the vector-ALU attention kernel with one
+    // head of width C, which has no such granularity.
+    const int bk = dtype == SDMI_F32 ? 32 : 64;
+    if (N % bk != 0) {
+      void* v = ws.get("vv", act_bytes(B, H, W, C));
+      SDMI_TRY(gemm(nrm, C, a.v.w, a.v.bias, C, 1, v, C, 1, 1, B * N, 1, B * N, 0, nullptr, 0, 0, s));
+      if (!ws.dry) {
+        AttentionArgs at;
+        at.q = q; at.ldq = C; at.k = k; at.ldk = C; at.v = v; at.ldv = C; at.out = o; at.ldo = C;
+        at.B = B; at.heads = 1; at.Nq = N; at.Nk = N; at.d = C; at.scale = scale; at.dtype = dtype; at.impl = 1;
+        SDMI_TRY(attention(at, s));
+      }
+      SDMI_TRY(gemm(o, C, a.proj.w, a.proj.bias, C, 1, y->p, C, 1, 1, B * N, 1, B * N, 0, x.p, C, 0, s));
+      return SDMI_OK;
+    }
     for (int b = 0; b < B; ++b) {
       const char* hb = (const char*)nrm + (size_t)b * N * C * esz;
       const char* qb = (const char*)q + (size_t)b * N * C * esz;

@@ -412,3 +412,34 @@ def test_txt2img_from_token_ids():
     plain = device_latent_diffusion(4, "crossattn", "fp16")
     with pytest.raises(NotImplementedError):
         plain.get_learned_conditioning(c_ids)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "fp16"])
+def test_vae_sizes_whose_token_count_is_no_multiple_of_64(dt):
+    """The reference's autoencoder takes any latent size (Decoder.forward :496 has no size condition, the encoder
+    needs multiples of 8 only); the mid-block attention's two-GEMM path contracts over the tokens in whole K-tiles,
+    other token counts (here 35, 54 and 45) take the vector-ALU attention kernel.  Against the fp32 CPU oracle."""
+    from oracle import vae_ref
+    from _util import structure as S, synth
+    model = device_latent_diffusion(4, "crossattn", dt)
+    est = S.vae_encoder_structure(S.sd_v1_ddconfig(), 4)
+    dst = S.vae_decoder_structure(S.sd_v1_ddconfig(), 4)
+    vsd = synth.synth_state_dict(S.vae_encoder_param_shapes(est), 0)
+    vsd.update(synth.synth_state_dict(S.vae_decoder_param_shapes(dst), 0))
+    torch.set_num_threads(16)
+    bar = 1e-4 if dt == "fp32" else 2e-2
+    for shape in ((1, 4, 5, 7), (2, 4, 9, 6)):
+        z = synth.normal(61, f"oddvae.z.{shape[2]}x{shape[3]}", shape)
+        dec = model.first_stage_model.decode(z.cuda())
+        torch.cuda.synchronize()
+        ref = vae_ref.decode(vsd, dst, z)
+        assert tuple(dec.shape) == (shape[0], 3, 8 * shape[2], 8 * shape[3])
+        e = max_rel_err(dec.cpu(), ref)
+        print(f"vae decode {shape} {dt}: {e:.3e}")
+        assert e < bar
+    x = synth.uniform(62, "oddvae.image", (1, 3, 72, 40), -1.0, 1.0)
+    post = model.encode_first_stage(x.cuda())
+    torch.cuda.synchronize()
+    e = max_rel_err(post.parameters.cpu(), vae_ref.encode(vsd, est, x))
+    print(f"vae encode 72x40 {dt}: {e:.3e}")
+    assert tuple(post.parameters.shape) == (1, 8, 9, 5) and e < bar

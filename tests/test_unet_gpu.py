@@ -163,3 +163,30 @@ def test_errors_are_loud():
         net(torch.zeros(1, 4, 20, 20).cuda(), g["t"].cuda(), context=g["ctx"].float().cuda())
     with pytest.raises(AssertionError, match="class-conditional"):
         net(g["x"].cuda(), g["t"].cuda(), context=g["ctx"].float().cuda(), y=torch.zeros(1))
+
+
+@pytest.mark.parametrize("hw", [(24, 40), (8, 72)])
+def test_non_square_latents_against_the_oracle(hw):
+    """Latent sizes with H != W (the scripts take --H and --W separately, txt2img.py:240-257), an odd batch and a
+    different timestep per sample: no golden holds such a call, so the fp32 CPU oracle (itself pinned to the
+    reference by g3) computes the expected output here on the same synthesised weights."""
+    import importlib
+    import os
+    from oracle import unet_ref
+    S = importlib.import_module("stable-diffusion_amd.structure")
+    synth = importlib.import_module("stable-diffusion_amd.synth")
+    cfg = S.sd_v1_unet_config(4)
+    st = S.unet_structure(**cfg)
+    h, w = hw
+    x = synth.normal(5, f"nsq.x.{h}x{w}", (3, 4, h, w))
+    ctx = synth.normal(6, "nsq.ctx", (3, 77, 768)).half().float()
+    t = torch.tensor([981, 500, 21], dtype=torch.long)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref = unet_ref.unet_forward(synth.synth_state_dict(S.unet_param_shapes(st), 0), st, x, t, ctx)
+    for dt in ("fp32", "fp16"):
+        out = device_unet(4, dt)(x.cuda(), t.cuda(), context=ctx.cuda())
+        torch.cuda.synchronize()
+        assert tuple(out.shape) == (3, 4, h, w)
+        err = max_rel_err(out.cpu(), ref)
+        print(f"non-square {h}x{w} {dt}: max_rel_err {err:.3e}")
+        assert err < BAR[dt], (hw, dt, err)

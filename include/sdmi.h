@@ -168,7 +168,8 @@ int sdmi_vae_decoder_set_weight(sdmi_vae_decoder* v, const char* key, const void
 int sdmi_vae_decoder_finalize(sdmi_vae_decoder* v, void* stream);
 /* out = Decoder(post_quant_conv(z * z_scale)); z fp32 NCHW [batch][z_channels][h][w],
  * out fp32 NCHW [batch][out_ch][8h][8w].  z_scale = 1/scale_factor for decode_first_stage, 1 for
- * AutoencoderKL.decode. */
+ * AutoencoderKL.decode.  Any h, w (the mid-block attention runs on the matrix cores when h * w is a multiple of 64,
+ * 32 in fp32 mode, which every latent behind the UNet is, and on the vector ALU otherwise). */
 int sdmi_vae_decoder_forward(sdmi_vae_decoder* v, const void* z, float z_scale, void* out, int batch,
                              int h, int w, void* stream);
 void sdmi_vae_decoder_destroy(sdmi_vae_decoder* v);
